@@ -1,0 +1,319 @@
+/* detmath.h — bit-reproducible scalar math shared by the HIP kernels, the host
+ * library and (by inclusion) the CPU oracle and the reference-kernel shim.
+ *
+ * Why this exists: the reference kernel calls the OpenCL built-ins cos, log, pow,
+ * pown, atan2pi, sqrt, normalize, mix, sign, min, max, clamp, fabs, dot, cross
+ * (/root/reference/src/render.cl:151-153,157,162,177,383,390,427-462,480). OpenCL
+ * leaves their results implementation-defined within ULP bounds (cos <=4, log <=3,
+ * pow <=16, atan2pi <=6 ulp; + - * exact IEEE). A path tracer is chaotic: a 1-ulp
+ * difference flips a hit/miss or a `material->x > random_float()` branch, so parity
+ * "within 1e-4 per pixel" is only reachable when every realisation of the kernel
+ * uses the SAME rounding everywhere. detmath pins one realisation that uses nothing
+ * but IEEE-754 correctly rounded + - * / sqrt, conversions and integer ops, so the
+ * x86-64 build (gcc/clang, -ffp-contract=off) and the gfx950 build (hipcc,
+ * -ffp-contract=off, default correctly-rounded f32 divide/sqrt, f32 denormals on)
+ * produce identical bits. tests/test_detmath.py checks the ULP bounds against libm.
+ *
+ * Every file that includes this header MUST be compiled with -ffp-contract=off.
+ * Polynomial coefficients: simple-raytracer_amd/tools/gen_detmath_coeffs.py.
+ */
+#ifndef SRT_DETMATH_H
+#define SRT_DETMATH_H
+
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define DM_FN __host__ __device__ static __forceinline__
+#else
+#define DM_FN static inline
+#endif
+
+#if defined(__HIP_DEVICE_COMPILE__)
+#define DM_SQRTF(x) __builtin_sqrtf(x)
+#define DM_SQRT(x) __builtin_sqrt(x)
+#else
+#define DM_SQRTF(x) __builtin_sqrtf(x)
+#define DM_SQRT(x) __builtin_sqrt(x)
+#endif
+
+/* ---- bit casts ------------------------------------------------------------ */
+DM_FN uint32_t dm_f2u(float f) {
+	uint32_t u;
+	__builtin_memcpy(&u, &f, 4);
+	return u;
+}
+DM_FN float dm_u2f(uint32_t u) {
+	float f;
+	__builtin_memcpy(&f, &u, 4);
+	return f;
+}
+DM_FN uint64_t dm_d2u(double d) {
+	uint64_t u;
+	__builtin_memcpy(&u, &d, 8);
+	return u;
+}
+DM_FN double dm_u2d(uint64_t u) {
+	double d;
+	__builtin_memcpy(&d, &u, 8);
+	return d;
+}
+
+#define DM_INF_F dm_u2f(0x7f800000u)
+#define DM_NAN_F dm_u2f(0x7fc00000u)
+
+/* ---- the "loose" OpenCL built-ins, pinned --- */
+/* OpenCL C 6.15.4: fmin-less integer-style definitions for min/max. */
+DM_FN float dm_min(float x, float y) { return y < x ? y : x; }
+DM_FN float dm_max(float x, float y) { return x < y ? y : x; }
+DM_FN float dm_clamp(float x, float lo, float hi) { return dm_min(dm_max(x, lo), hi); }
+DM_FN float dm_fabs(float x) { return dm_u2f(dm_f2u(x) & 0x7fffffffu); }
+/* sign(): 1 for x>0, -1 for x<0, the (signed) zero itself for +-0, 0 for NaN. */
+DM_FN float dm_sign(float x) {
+	if (x > 0.0f) return 1.0f;
+	if (x < 0.0f) return -1.0f;
+	if (x == 0.0f) return x;
+	return 0.0f;
+}
+/* mix(x, y, a) = x + (y - x) * a */
+DM_FN float dm_mix(float x, float y, float a) { return x + (y - x) * a; }
+/* sqrt is IEEE correctly rounded on both targets. */
+DM_FN float dm_sqrtf(float x) { return DM_SQRTF(x); }
+
+/* ---- cos(x): accurate for |x| <= ~8 (the kernel feeds [0, 2*pi]) ----------- */
+/* Cody-Waite reduction by pi/2 split into 11+11+11 bit chunks + float tail, so
+ * k*C1..k*C3 are exact for k < 2^13; then degree-3-in-z tails for sin and cos. */
+DM_FN float dm_cosf(float x) {
+	const float TWO_OVER_PI = 6.36619747e-01f;
+	const float C1 = 1.5703125f;                /* 0x3fc90000 */
+	const float C2 = 4.83751297e-04f;           /* 0x39fda000 */
+	const float C3 = 7.54953362e-08f;           /* 0x33a22000 */
+	const float C4 = 2.56334407e-12f;           /* 0x2c34611a */
+	float ax = dm_fabs(x);
+	if (!(ax < 16384.0f)) {
+		/* out of the supported range (or NaN/inf): NaN for non-finite, else best effort */
+		if (!(ax < DM_INF_F)) return DM_NAN_F;
+	}
+	int k = (int)(ax * TWO_OVER_PI + 0.5f);
+	float fk = (float)k;
+	float r = ax - fk * C1;
+	r = r - fk * C2;
+	r = r - fk * C3;
+	r = r - fk * C4;
+	float z = r * r;
+	int odd = k & 1;
+	/* coefficients: sin tail (odd quadrants) or cos tail (even quadrants) */
+	float c0 = odd ? -1.66666642e-01f : 4.16666642e-02f;
+	float c1 = odd ? 8.33272468e-03f : -1.38882792e-03f;
+	float c2 = odd ? -1.95828557e-04f : 2.45428964e-05f;
+	float p = c0 + z * (c1 + z * c2);
+	float s_res = r + (r * z) * p;                       /* sin(r) */
+	float c_res = ((z * z) * p - 0.5f * z) + 1.0f;       /* cos(r) */
+	float res = odd ? s_res : c_res;
+	/* cos(x): k&3 = 0: cos r, 1: -sin r, 2: -cos r, 3: sin r */
+	int neg = ((k + 1) >> 1) & 1;
+	return neg ? -res : res;
+}
+
+/* ---- log(x), natural, full float domain ----------------------------------- */
+DM_FN float dm_logf(float x) {
+	const float LN2_HI = 6.93138123e-01f;   /* 0x3f317180 */
+	const float LN2_LO = 9.05800061e-06f;   /* 0x3717f7d1 */
+	const float L0 = 6.66666687e-01f;
+	const float L1 = 4.00001287e-01f;
+	const float L2 = 2.85499692e-01f;
+	const float L3 = 2.33534276e-01f;
+	uint32_t ix = dm_f2u(x);
+	int k = 0;
+	if (ix < 0x00800000u || (ix >> 31)) {
+		if ((ix << 1) == 0) return -DM_INF_F;          /* log(+-0) = -inf */
+		if (ix >> 31) return DM_NAN_F;                 /* log(<0) = NaN  */
+		k -= 25;                                       /* subnormal: scale up */
+		x = x * 33554432.0f;
+		ix = dm_f2u(x);
+	}
+	if (ix >= 0x7f800000u) return x;                   /* inf or NaN */
+	k += (int)(ix >> 23) - 127;
+	ix &= 0x007fffffu;
+	/* normalise the mantissa to [sqrt(1/2), sqrt(2)) */
+	uint32_t i = (ix + 0x4afb20u) & 0x00800000u;
+	x = dm_u2f(ix | (i ^ 0x3f800000u));
+	k += (int)(i >> 23);
+	float f = x - 1.0f;
+	float s = f / (2.0f + f);
+	float z = s * s;
+	float R = z * (L0 + z * (L1 + z * (L2 + z * L3)));
+	float hfsq = (0.5f * f) * f;
+	float dk = (float)k;
+	return dk * LN2_HI + (f - (hfsq - (s * (hfsq + R) + dk * LN2_LO)));
+}
+
+/* ---- double-precision helpers for pow / atan2pi (once per escaping path) --- */
+/* log(x) for finite normal positive double x, rel. error ~1e-16. */
+DM_FN double dm_log_pos_d(double x) {
+	uint64_t ux = dm_d2u(x);
+	int k = (int)(ux >> 52) - 1023;
+	ux = (ux & 0x000fffffffffffffull) | 0x3ff0000000000000ull;
+	double m = dm_u2d(ux);                              /* [1, 2) */
+	if (m > 1.4142135623730951) {
+		m = m * 0.5;
+		k += 1;
+	}
+	double s = (m - 1.0) / (m + 1.0);
+	double z = s * s;
+	/* atanh series: log m = 2 s (1 + z/3 + z^2/5 + ... + z^11/23) */
+	double p = 1.0 / 23.0;
+	p = p * z + 1.0 / 21.0;
+	p = p * z + 1.0 / 19.0;
+	p = p * z + 1.0 / 17.0;
+	p = p * z + 1.0 / 15.0;
+	p = p * z + 1.0 / 13.0;
+	p = p * z + 1.0 / 11.0;
+	p = p * z + 1.0 / 9.0;
+	p = p * z + 1.0 / 7.0;
+	p = p * z + 1.0 / 5.0;
+	p = p * z + 1.0 / 3.0;
+	p = p * z + 1.0;
+	return (double)k * 0.6931471805599453 + (2.0 * s) * p;
+}
+
+/* exp(t) for |t| < 700, rel. error ~1e-16. */
+DM_FN double dm_exp_d(double t) {
+	const double INV_LN2 = 1.4426950408889634;
+	const double LN2_HI = 0x1.62e42fee00000p-1;
+	const double LN2_LO = 0x1.a39ef35793c76p-33;
+	double fn = t * INV_LN2;
+	int n = (int)(fn < 0.0 ? fn - 0.5 : fn + 0.5);
+	double dn = (double)n;
+	double r = (t - dn * LN2_HI) - dn * LN2_LO;
+	/* Taylor to r^13/13!, |r| <= 0.35 */
+	double p = 1.0 / 6227020800.0;
+	p = p * r + 1.0 / 479001600.0;
+	p = p * r + 1.0 / 39916800.0;
+	p = p * r + 1.0 / 3628800.0;
+	p = p * r + 1.0 / 362880.0;
+	p = p * r + 1.0 / 40320.0;
+	p = p * r + 1.0 / 5040.0;
+	p = p * r + 1.0 / 720.0;
+	p = p * r + 1.0 / 120.0;
+	p = p * r + 1.0 / 24.0;
+	p = p * r + 1.0 / 6.0;
+	p = p * r + 0.5;
+	p = p * r + 1.0;
+	p = p * r + 1.0;
+	/* scale by 2^n, n in [-1020, 1020] here */
+	double sc = dm_u2d((uint64_t)(n + 1023) << 52);
+	return p * sc;
+}
+
+/* pow(x, y), float in / float out, computed in double: <1 ulp. Follows the
+ * OpenCL/C99 special-case table for the cases a renderer can reach. */
+DM_FN float dm_powf(float x, float y) {
+	if (y == 0.0f) return 1.0f;
+	if (x == 1.0f) return 1.0f;
+	if (x != x || y != y) return DM_NAN_F;
+	uint32_t uy = dm_f2u(y);
+	float ay = dm_fabs(y);
+	/* integer-ness / parity of y */
+	int y_is_int = 0, y_is_odd = 0;
+	if (ay >= 16777216.0f) {
+		y_is_int = 1;
+	} else {
+		int iy = (int)ay;
+		if ((float)iy == ay) {
+			y_is_int = 1;
+			y_is_odd = iy & 1;
+		}
+	}
+	float ax = dm_fabs(x);
+	int neg_result = 0;
+	if (dm_f2u(x) >> 31) {
+		if (ax == 0.0f || ax == DM_INF_F) {
+			neg_result = y_is_odd;
+		} else {
+			if (!y_is_int) return DM_NAN_F;
+			neg_result = y_is_odd;
+		}
+	}
+	float res;
+	if (ax == 0.0f) {
+		res = (uy >> 31) ? DM_INF_F : 0.0f;
+	} else if (ax == DM_INF_F) {
+		res = (uy >> 31) ? 0.0f : DM_INF_F;
+	} else if (ay == DM_INF_F) {
+		if (ax == 1.0f) res = 1.0f;
+		else res = ((ax > 1.0f) != (int)(uy >> 31)) ? DM_INF_F : 0.0f;
+	} else {
+		double t = (double)y * dm_log_pos_d((double)ax);
+		if (t > 90.0) res = DM_INF_F;
+		else if (t < -105.0) res = 0.0f;
+		else res = (float)dm_exp_d(t);
+	}
+	return neg_result ? -res : res;
+}
+
+/* pown(double, int) by binary exponentiation; pown(x,5) = x * ((x*x)*(x*x)).
+ * (reference: shlick_reflectance, src/render.cl:177, evaluated in fp64) */
+DM_FN double dm_pown_d(double x, int n) {
+	unsigned un = n < 0 ? 0u - (unsigned)n : (unsigned)n;
+	double result = 1.0, base = x;
+	while (un) {
+		if (un & 1u) result = result * base;
+		un >>= 1;
+		if (un) base = base * base;
+	}
+	return n < 0 ? 1.0 / result : result;
+}
+
+/* atan(t) for t in [0,1], double, abs error < 1e-13 */
+DM_FN double dm_atan01_d(double t) {
+	double off = 0.0;
+	if (t > 0.41421356237309503) {
+		t = (t - 1.0) / (t + 1.0);
+		off = 0.7853981633974483;
+	}
+	double z = t * t;
+	double p = 1.0 / 29.0;
+	p = -(p * z) + 1.0 / 27.0;
+	p = -(p * z) + 1.0 / 25.0;
+	p = -(p * z) + 1.0 / 23.0;
+	p = -(p * z) + 1.0 / 21.0;
+	p = -(p * z) + 1.0 / 19.0;
+	p = -(p * z) + 1.0 / 17.0;
+	p = -(p * z) + 1.0 / 15.0;
+	p = -(p * z) + 1.0 / 13.0;
+	p = -(p * z) + 1.0 / 11.0;
+	p = -(p * z) + 1.0 / 9.0;
+	p = -(p * z) + 1.0 / 7.0;
+	p = -(p * z) + 1.0 / 5.0;
+	p = -(p * z) + 1.0 / 3.0;
+	p = -(p * z) + 1.0;
+	return off + t * p;
+}
+
+/* atan2pi(y, x) = atan2(y, x) / pi, OpenCL C 7.5.1 edge cases. */
+DM_FN float dm_atan2pif(float y, float x) {
+	if (x != x || y != y) return DM_NAN_F;
+	uint32_t sy = dm_f2u(y) >> 31, sx = dm_f2u(x) >> 31;
+	float ax = dm_fabs(x), ay = dm_fabs(y);
+	float r;
+	if (ay == 0.0f) {
+		r = sx ? 1.0f : 0.0f;
+	} else if (ax == 0.0f) {
+		r = 0.5f;
+	} else if (ay == DM_INF_F) {
+		r = (ax == DM_INF_F) ? (sx ? 0.75f : 0.25f) : 0.5f;
+	} else if (ax == DM_INF_F) {
+		r = sx ? 1.0f : 0.0f;
+	} else {
+		double dx = (double)ax, dy = (double)ay;
+		int swap = dy > dx;
+		double t = swap ? dx / dy : dy / dx;
+		double a = dm_atan01_d(t);
+		if (swap) a = 1.5707963267948966 - a;
+		if (sx) a = 3.141592653589793 - a;
+		r = (float)(a * 0.3183098861837907);
+	}
+	return sy ? -r : r;
+}
+
+#endif /* SRT_DETMATH_H */

@@ -1,0 +1,141 @@
+/* srt_abi.h — the C ABI of the MI355X path-tracing library (libsrt_hip.so).
+ *
+ * It replaces exactly one thing in the reference: the boost.compute/OpenCL dispatch
+ * inside `class Tracer` (/root/reference/include/tracer.hpp:26-88,
+ * /root/reference/src/tracer.cpp:11-116). Every entry point names the reference
+ * member it stands in for. Records are passed as raw bytes in the layouts of
+ * srt_types.h. Plain pointers and sizes only: no C++ types, no torch types.
+ *
+ * Status codes: 0 = ok, anything else = failure; srt_last_error() returns the text
+ * (the C++ wrapper simple-raytracer_amd/host/tracer.hpp turns it into an exception,
+ * as boost.compute throws in the reference, src/tracer.cpp:20-26).
+ *
+ * Threading: a handle is NOT thread-safe (the reference drives its Tracer from the
+ * SDL main thread only). All device work of a handle is ordered on one HIP stream.
+ */
+#ifndef SRT_ABI_H
+#define SRT_ABI_H
+
+#include "srt_types.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct srt_tracer srt_tracer; /* opaque */
+
+enum {
+	SRT_OK = 0,
+	SRT_ERR_INVALID = 1, /* bad argument */
+	SRT_ERR_HIP = 2,     /* a HIP runtime call failed (no device, OOM, launch error) */
+	SRT_ERR_STATE = 3    /* call order violated (e.g. render before a skybox exists) */
+};
+
+/* Deterministic work counters of the trace kernel, summed over all render calls since
+ * the last srt_reset_counters(). Schedule independent; equal to the oracle's. */
+typedef struct srt_counters {
+	uint64_t paths;      /* (pixel, sample) pairs traced */
+	uint64_t rays;       /* closest-hit queries = path segments (render.cl:404) */
+	uint64_t sky;        /* segments that escaped to the sky (render.cl:463-467) */
+	uint64_t tri_tests;  /* triangle tests executed (render.cl:331) */
+	uint64_t tri_pass_u; /* triangle tests that passed the u-range check (render.cl:260) */
+	uint64_t nan_pixels; /* pixels whose colour of a dispatch was NaN */
+} srt_counters;
+
+/* ---- life cycle ------------------------------------------------------------- */
+
+/* Tracer::Tracer(width, height) — src/tracer.cpp:11-68. Selects HIP device
+ * `device_index`, creates the stream, the float3 canvas (16 B/pixel) and the ARGB8
+ * output buffer. width/height are fixed for the life of the handle (no resize). */
+int srt_create(int width, int height, int device_index, srt_tracer **out);
+
+/* ~Tracer (implicit in the reference). */
+void srt_destroy(srt_tracer *t);
+
+/* Text of the last failure on this handle (or of srt_create when t == NULL). */
+const char *srt_last_error(const srt_tracer *t);
+
+/* ---- inputs ------------------------------------------------------------------ */
+
+/* The skybox upload of src/tracer.cpp:42-55, minus the PNG decode: `rgba` is the
+ * RGBA32F image stb would have produced (row 0 = bottom after the vertical flip),
+ * width*height*4 floats. Sampled like CL_ADDRESS_CLAMP_TO_EDGE | CL_FILTER_LINEAR with
+ * normalized coordinates (src/tracer.cpp:47-48) in exact float arithmetic. */
+int srt_set_skybox(srt_tracer *t, const float *rgba, int width, int height);
+
+/* Tracer::update_scene — src/tracer.cpp:70-96. Copies the three arrays (any may be
+ * empty: an empty scene renders pure sky) and latches *scene (SceneData reaches the
+ * kernel only here, never in render). scene->num_shapes is overwritten by n_shapes,
+ * as src/tracer.cpp:94 does. Also runs the world-space triangle pre-pass. */
+int srt_update_scene(srt_tracer *t, const srt_shape *shapes, size_t n_shapes, const srt_triangle *triangles,
+                     size_t n_triangles, const srt_material *materials, size_t n_materials,
+                     const srt_scene_data *scene);
+
+/* Tracer::clear_canvas — src/tracer.cpp:98-101. */
+int srt_clear_canvas(srt_tracer *t);
+
+/* ---- the hot path -------------------------------------------------------------- */
+
+/* Tracer::render(ticks_stopped, output) — src/tracer.cpp:103-116: launches the trace
+ * kernel (canvas += mean radiance of options->num_samples paths per pixel), the
+ * resolve kernel (canvas/ticks_stopped -> ACES -> sqrt -> A,R,G,B bytes) and copies
+ * width*height*4 bytes to argb_out; returns when they are in host memory.
+ * With a row partition set (below) only the owned rows are written, packed. */
+int srt_render(srt_tracer *t, const srt_render_data *options, uint32_t ticks_stopped, uint8_t *argb_out);
+
+/* The two halves of srt_render, asynchronous on the handle's stream, for callers
+ * that keep results on the device (bench, multi-GPU gather). */
+int srt_trace(srt_tracer *t, const srt_render_data *options);      /* `render` kernel, render.cl:483 */
+int srt_resolve(srt_tracer *t, uint32_t ticks_stopped);             /* `average` kernel, render.cl:525 */
+int srt_synchronize(srt_tracer *t);
+
+/* ---- results / introspection ---------------------------------------------------- */
+
+/* Copies the accumulation canvas (owned rows, packed): n_owned_rows*width float4. */
+int srt_read_canvas(srt_tracer *t, float *rgba_out);
+/* Copies the resolved image (owned rows, packed): n_owned_rows*width*4 bytes. */
+int srt_read_argb(srt_tracer *t, uint8_t *argb_out);
+int srt_get_counters(srt_tracer *t, srt_counters *out);
+/* Select the instrumented trace-kernel variant that also fills tri_tests/tri_pass_u
+ * (one extra VALU op per triangle test); results are unchanged. Default off. */
+int srt_set_count_triangles(srt_tracer *t, int enable);
+int srt_reset_counters(srt_tracer *t);
+/* Device time of the most recent trace / resolve launch, from HIP events recorded on
+ * the handle's stream around the kernel (milliseconds). Synchronises the stream. */
+int srt_last_kernel_ms(srt_tracer *t, float *trace_ms, float *resolve_ms);
+/* Device pointers of the handle's buffers, for zero-copy hand-off (e.g. to a
+ * torch.distributed gather): canvas = owned_rows*width*16 B, argb = owned_rows*width*4 B. */
+int srt_device_buffers(srt_tracer *t, void **canvas, size_t *canvas_bytes, void **argb, size_t *argb_bytes);
+/* Use caller-owned device memory (>= owned_rows*width*16 B) as the canvas, and/or a
+ * caller-owned hipStream_t for all launches. NULL restores the handle's own. */
+int srt_bind_canvas(srt_tracer *t, void *device_canvas, size_t bytes);
+int srt_bind_stream(srt_tracer *t, void *hip_stream);
+
+/* ---- multi-GPU row partition (new; the reference is single-device) -------------- */
+
+/* Rank `rank` of `world` owns the row blocks b with b % world == rank, a block being
+ * `rows_per_block` scanlines; the canvas/ARGB buffers hold only those rows, packed in
+ * increasing block order. Pixel seeds use the GLOBAL pixel index (render.cl:488,496),
+ * so any partition reproduces the single-device image bit for bit. Clears the canvas.
+ * world == 1 restores the full image. */
+int srt_set_partition(srt_tracer *t, int rank, int world, int rows_per_block);
+
+/* Pure host helpers (no GPU needed) describing that layout. */
+int srt_partition_owned_rows(int height, int rank, int world, int rows_per_block);
+/* padded_rows = rows every rank sends in an equal-count gather (max over ranks). */
+int srt_partition_padded_rows(int height, int world, int rows_per_block);
+/* Global y of packed local row `local_row` of `rank`, or -1 when it is padding. */
+int srt_partition_global_row(int height, int rank, int world, int rows_per_block, int local_row);
+/* Unpermute on the host: gathered = world * padded_rows rows of `row_bytes` each
+ * (rank-major); image = height rows. */
+int srt_partition_unpermute(const void *gathered, void *image, int height, int world, int rows_per_block,
+                            size_t row_bytes);
+
+/* Library / build identification, e.g. "srt-hip gfx950 parity fp-contract=off". */
+const char *srt_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif /* SRT_ABI_H */

@@ -74,7 +74,7 @@ class Oracle:
         return getattr(self.lib, self.px + name)
 
     # ---- kernels ---------------------------------------------------------------
-    def render(self, rd, sd, shapes, tris, mats, sky, canvas=None, rows=None, nthreads=0, counters=False):
+    def render(self, rd, sd, shapes, tris, mats, sky, canvas=None, rows=None, nthreads=0, counters=False, row_stride=1):
         """`render` kernel over rows [y0,y1) (default all): canvas += colour. Returns the
         canvas (h, w, 4) float32, and the counter dict when counters=True (oracle only)."""
         shapes, tris, mats, rd, sd = _scene_arrays(shapes, tris, mats, rd, sd)
@@ -84,12 +84,17 @@ class Oracle:
         y0, y1 = (0, h) if rows is None else rows
         sky = np.ascontiguousarray(sky, np.float32)
         args = [_p(rd), _p(sd), _p(canvas), _p(shapes), _p(tris), _p(mats), _p(sky),
-                C.c_int(sky.shape[1]), C.c_int(sky.shape[0]), C.c_int(y0), C.c_int(y1), C.c_int(nthreads)]
+                C.c_int(sky.shape[1]), C.c_int(sky.shape[0]), C.c_int(y0), C.c_int(y1)]
         ctr = None
         if self.kind == "oracle":
             ctr = np.zeros(len(COUNTER_NAMES), np.uint64)
-            args.append(_p(ctr))
-        self._f("render")(*args)
+            args += [C.c_int(row_stride), C.c_int(nthreads), _p(ctr)]
+            self.lib.orc_render_strided.restype = None
+            self.lib.orc_render_strided(*args)
+        else:
+            assert row_stride == 1
+            args.append(C.c_int(nthreads))
+            self._f("render")(*args)
         if counters:
             return canvas, dict(zip(COUNTER_NAMES, (int(v) for v in ctr))) if ctr is not None else None
         return canvas

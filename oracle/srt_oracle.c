@@ -410,9 +410,23 @@ static v3 render_pixel(const srt_render_data *data, const scene_t *scene, int px
 
 /* The `render` kernel over rows [y0, y1): canvas[id] += colour. canvas is the full
  * width*height image of 16-byte float3 (x,y,z,pad). counters may be NULL. */
+void orc_render_strided(const srt_render_data *data, const srt_scene_data *scene_data, float *canvas,
+                        const srt_shape *shapes, const srt_triangle *triangles, const srt_material *materials,
+                        const float *sky_rgba, int sky_w, int sky_h, int y0, int y1, int ystride, int nthreads,
+                        uint64_t *counters);
+
 void orc_render(const srt_render_data *data, const srt_scene_data *scene_data, float *canvas,
                 const srt_shape *shapes, const srt_triangle *triangles, const srt_material *materials,
                 const float *sky_rgba, int sky_w, int sky_h, int y0, int y1, int nthreads, uint64_t *counters) {
+	orc_render_strided(data, scene_data, canvas, shapes, triangles, materials, sky_rgba, sky_w, sky_h, y0, y1, 1, nthreads,
+	                   counters);
+}
+
+/* rows y0, y0+ystride, ... < y1 (a strided sample of the frame for the CPU baseline) */
+void orc_render_strided(const srt_render_data *data, const srt_scene_data *scene_data, float *canvas,
+                        const srt_shape *shapes, const srt_triangle *triangles, const srt_material *materials,
+                        const float *sky_rgba, int sky_w, int sky_h, int y0, int y1, int ystride, int nthreads,
+                        uint64_t *counters) {
 	scene_t scene = {scene_data, shapes, triangles, materials, sky_rgba, sky_w, sky_h};
 	uint64_t total[ORC_C_COUNT];
 	memset(total, 0, sizeof total);
@@ -425,8 +439,11 @@ void orc_render(const srt_render_data *data, const srt_scene_data *scene_data, f
 	{
 		uint64_t ctr[ORC_C_COUNT];
 		memset(ctr, 0, sizeof ctr);
+		if (ystride < 1) ystride = 1;
+		const int nrows = y1 > y0 ? (y1 - y0 + ystride - 1) / ystride : 0;
 #pragma omp for schedule(dynamic, 1)
-		for (int y = y0; y < y1; y++) {
+		for (int r = 0; r < nrows; r++) {
+			const int y = y0 + r * ystride;
 			for (int x = 0; x < data->width; x++) {
 				v3 c = render_pixel(data, &scene, x, y, ctr);
 				float *out = canvas + 4 * ((size_t)y * data->width + x);

@@ -1,0 +1,53 @@
+"""hipcc recipes for csrc/ -> lib/libsrt_hip.so (in-tree, so it travels with gpurun).
+
+-ffp-contract=off is load-bearing: parity with the CPU oracle needs unfused IEEE
+arithmetic (DESIGN.md "Numerics"). hipcc's defaults -fhip-fp32-correctly-rounded-
+divide-sqrt and f32 denormal support stay ON (never pass -ffast-math,
+-fgpu-flush-denormals-to-zero or -fno-hip-fp32-correctly-rounded-divide-sqrt here).
+"""
+import os
+import shutil
+import subprocess
+from pathlib import Path
+
+PKG = Path(__file__).resolve().parent
+CSRC = PKG / "csrc"
+LIBDIR = PKG / "lib"
+LIB = LIBDIR / "libsrt_hip.so"
+SOURCES = ["kernels.hip", "srt_abi.hip"]
+HEADERS = ["detmath.h", "device_types.h", "../../include/srt_abi.h", "../../include/srt_types.h"]
+ARCH = "gfx950"
+FLAGS = ["-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-fno-gpu-rdc", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function"]
+
+
+def hipcc():
+    return os.environ.get("HIPCC") or shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+
+
+def stale():
+    if not LIB.exists():
+        return True
+    t = LIB.stat().st_mtime
+    deps = [CSRC / s for s in SOURCES] + [(CSRC / h).resolve() for h in HEADERS] + [Path(__file__)]
+    return any(d.stat().st_mtime > t for d in deps)
+
+
+def build_hip(force=False, verbose=False, extra_flags=()):
+    """Compile the HIP library if sources are newer than the .so. Returns its path."""
+    if not force and not stale():
+        return LIB
+    LIBDIR.mkdir(exist_ok=True)
+    cmd = [hipcc(), *FLAGS, *extra_flags, "-shared", "-o", str(LIB)] + [str(CSRC / s) for s in SOURCES]
+    if verbose:
+        print(" ".join(cmd))
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("hipcc failed:\n" + r.stdout + r.stderr)
+    if verbose and r.stderr:
+        print(r.stderr)
+    return LIB
+
+
+if __name__ == "__main__":
+    import sys
+    print(build_hip(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,69 @@
+/* device_types.h — device-side scene representation shared by kernels.hip and
+ * srt_abi.hip. Not part of the public ABI. */
+#ifndef SRT_DEVICE_TYPES_H
+#define SRT_DEVICE_TYPES_H
+
+#include <stdint.h>
+
+#include "../../include/srt_types.h"
+
+/* Compact per-shape record for the wave-uniform intersection loop. Every lane of a
+ * wave tests the SAME shape at the same time (array order, render.cl:299), so these
+ * are fetched with scalar loads into SGPRs, not staged per lane.
+ *   sphere: f[0..2] centre, f[3] radius*radius (same product as render.cl:187)
+ *   plane : f[0..2] position, f[3..5] normal
+ *   model : f[0..2] bounding_min, f[3..5] bounding_max, a = first world triangle,
+ *           b = triangle count */
+struct LoopShape {
+	int32_t type;
+	uint32_t a;
+	uint32_t b;
+	int32_t _pad;
+	float f[8];
+};
+static_assert(sizeof(LoopShape) == 48, "LoopShape 48 B");
+
+/* World-space triangle written by the pre-pass: v0, e1 = v1 - v0, e2 = v2 - v0 with
+ * v = transform * pos in the operation order of render.cl:114-120, so each value is
+ * bit-identical to what the reference recomputes per ray (render.cl:325-328,247-248). */
+#define SRT_WTRI_FLOATS 9
+
+enum { SRT_CTR_RAYS = 0, SRT_CTR_SKY, SRT_CTR_TRI, SRT_CTR_TRI_PASS_U, SRT_CTR_NAN, SRT_CTR_PATHS, SRT_CTR_COUNT };
+
+struct TraceParams {
+	srt_render_data rd;
+	srt_scene_data sd;
+	const LoopShape *loop_shapes;
+	const srt_shape *shapes;
+	const srt_triangle *triangles;
+	const srt_material *materials;
+	const float *wtris;
+	const float *sky; /* RGBA32F */
+	float *canvas;    /* float4 per owned pixel, packed rows */
+	unsigned long long *counters;
+	int32_t sky_w, sky_h;
+	int32_t num_models;
+	int32_t rank, world, rows_per_block, owned_rows;
+};
+
+struct PrepassParams {
+	const srt_shape *shapes;
+	const srt_triangle *triangles;
+	const uint32_t *wtri_offset; /* per shape: first world triangle (models only) */
+	float *wtris;
+	int32_t num_shapes;
+	uint32_t num_triangles; /* size of the triangle array, for bounds clamping */
+};
+
+struct ResolveParams {
+	const float *canvas;
+	uint8_t *argb;
+	uint32_t num_steps;
+	uint32_t num_pixels;
+};
+
+void srt_launch_trace(const TraceParams &p, bool count_triangles, void *stream);
+void srt_launch_prepass(const PrepassParams &p, uint64_t total_wtris, void *stream);
+void srt_launch_resolve(const ResolveParams &p, void *stream);
+
+#endif

@@ -1,0 +1,477 @@
+// kernels.hip — hand-written gfx950 kernels for the path-tracing hot path.
+//
+// What they compute is the reference's `render` and `average` OpenCL kernels
+// (/root/reference/src/render.cl:483-535 and the helpers :114-481); how they compute
+// it is CDNA4-first and shares no structure with that file:
+//
+//  * srt_trace_kernel: ONE LANE PER PIXEL, persistent over that pixel's samples. The
+//    reference's three nested loops (samples x bounces x shapes) are flattened into a
+//    single loop over path SEGMENTS: a lane whose path ends (sky miss, bounce limit,
+//    show_normals) starts its next sample on the very next iteration instead of idling
+//    until the longest path of the wave ends; the wave leaves when a ballot shows no
+//    lane has samples left. Lane-private serial accumulation in sample order makes the
+//    canvas bit-identical to the reference's `color += trace(...)` (render.cl:518).
+//  * The shape loop index is wave-uniform, so shape records and world-space triangles
+//    arrive through SCALAR loads (s_load_dwordx*) into SGPRs and feed VALU ops as
+//    scalar operands: no per-lane loads, no LDS traffic and no VGPRs for scene data.
+//  * Winner data (normal, material) is fetched once per segment AFTER the loop, per
+//    lane, instead of at every improving hit as render.cl:311-312,336-343 do: only the
+//    last improving hit survives there, so deferring is exact.
+//  * Triangles are pre-transformed to world space once per scene (srt_prepass_kernel)
+//    in the reference's operation order, removing 63 of ~115 flops per triangle test.
+//  * No MFMA: nothing here is a contraction. Compiled with -ffp-contract=off; every
+//    float op is an IEEE add/mul/div/sqrt or a detmath.h routine so that results match
+//    the CPU oracle bit for bit (DESIGN.md "Numerics").
+#include <hip/hip_runtime.h>
+
+#include "detmath.h"
+#include "device_types.h"
+
+namespace {
+
+struct f3 {
+	float x, y, z;
+};
+
+__device__ __forceinline__ f3 mk(float x, float y, float z) { return f3{x, y, z}; }
+__device__ __forceinline__ f3 operator+(f3 a, f3 b) { return mk(a.x + b.x, a.y + b.y, a.z + b.z); }
+__device__ __forceinline__ f3 operator-(f3 a, f3 b) { return mk(a.x - b.x, a.y - b.y, a.z - b.z); }
+__device__ __forceinline__ f3 operator*(f3 a, f3 b) { return mk(a.x * b.x, a.y * b.y, a.z * b.z); }
+__device__ __forceinline__ f3 operator*(f3 a, float s) { return mk(a.x * s, a.y * s, a.z * s); }
+__device__ __forceinline__ f3 operator/(f3 a, float s) { return mk(a.x / s, a.y / s, a.z / s); }
+__device__ __forceinline__ f3 neg(f3 a) { return mk(-a.x, -a.y, -a.z); }
+// dot = (a.x*b.x + a.y*b.y) + a.z*b.z  (pinned)
+__device__ __forceinline__ float dot3(f3 a, f3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
+__device__ __forceinline__ f3 cross3(f3 a, f3 b) {
+	return mk(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+}
+__device__ __forceinline__ f3 normalize3(f3 a) { return a / dm_sqrtf(dot3(a, a)); }
+__device__ __forceinline__ f3 mix3(f3 x, f3 y, float a) {
+	return mk(dm_mix(x.x, y.x, a), dm_mix(x.y, y.y, a), dm_mix(x.z, y.z, a));
+}
+__device__ __forceinline__ f3 ld3(const srt_float3 &p) { return mk(p.x, p.y, p.z); }
+__device__ __forceinline__ f3 ld3(const float *p) { return mk(p[0], p[1], p[2]); }
+
+// column-major 4x4 times (v, w): ((m0*v.x + m1*v.y) + m2*v.z) + m3*w  (render.cl:114-120)
+__device__ __forceinline__ f3 mat_by_vec(const srt_float4 *m, f3 v, float w) {
+	return mk(((m[0].x * v.x + m[1].x * v.y) + m[2].x * v.z) + m[3].x * w,
+	          ((m[0].y * v.x + m[1].y * v.y) + m[2].y * v.z) + m[3].y * w,
+	          ((m[0].z * v.x + m[1].z * v.y) + m[2].z * v.z) + m[3].z * w);
+}
+
+// v - 2 (v.n) n  (render.cl:139-141)
+__device__ __forceinline__ f3 reflect3(f3 v, f3 n) { return v - n * (2.0f * dot3(v, n)); }
+
+// PCG-RXS-M-XS-32 (render.cl:143-148); (float)UINT_MAX == 2^32
+__device__ __forceinline__ float random_float(uint32_t &seed) {
+	seed = seed * 747796405u + 2891336453u;
+	uint32_t r = ((seed >> ((seed >> 28) + 4u)) ^ seed) * 277803737u;
+	r = (r >> 22) ^ r;
+	return (float)r * 2.3283064365386963e-10f; // exact: division by 2^32
+}
+
+// Box-Muller, theta drawn first (render.cl:150-154)
+__device__ __forceinline__ float random_normal(uint32_t &seed) {
+	float theta = 6.28318548f * random_float(seed);
+	float rho = dm_sqrtf(-2.0f * dm_logf(random_float(seed)));
+	return rho * dm_cosf(theta);
+}
+
+// fp64 Schlick (render.cl:173-178)
+__device__ __forceinline__ float schlick(float mu, float cos_theta) {
+	float r0 = (float)((1.0 - (double)mu) / (1.0 + (double)mu));
+	r0 = r0 * r0;
+	double x = 1.0 - (double)cos_theta;
+	double x5 = x * ((x * x) * (x * x)); // dm_pown_d(x, 5)
+	return (float)((double)r0 + (1.0 - (double)r0) * x5);
+}
+
+// global y of packed local row (include/srt_abi.h srt_set_partition)
+__device__ __forceinline__ int global_row(int local_row, int rank, int world, int rpb) {
+	int lb = local_row / rpb;
+	return (lb * world + rank) * rpb + (local_row - lb * rpb);
+}
+
+// Manual float bilinear, OpenCL 3.0 §8.2 CLAMP_TO_EDGE + LINEAR, normalized coords
+__device__ __forceinline__ f3 sample_sky(const float *__restrict__ sky, int W, int H, float s, float t) {
+	float fu = s * (float)W - 0.5f;
+	float fv = t * (float)H - 0.5f;
+	float cu = dm_clamp(fu, -1.0f, (float)W);
+	float cv = dm_clamp(fv, -1.0f, (float)H);
+	if (!(cu == cu)) cu = 0.0f;
+	if (!(cv == cv)) cv = 0.0f;
+	float x0f = __builtin_floorf(cu), y0f = __builtin_floorf(cv);
+	float a = fu - x0f, b = fv - y0f;
+	int x0 = (int)x0f, y0 = (int)y0f;
+	int i0 = min(max(x0, 0), W - 1), i1 = min(max(x0 + 1, 0), W - 1);
+	int j0 = min(max(y0, 0), H - 1), j1 = min(max(y0 + 1, 0), H - 1);
+	const float4 *img = reinterpret_cast<const float4 *>(sky);
+	float4 T00 = img[(size_t)j0 * W + i0];
+	float4 T10 = img[(size_t)j0 * W + i1];
+	float4 T01 = img[(size_t)j1 * W + i0];
+	float4 T11 = img[(size_t)j1 * W + i1];
+	float w00 = (1.0f - a) * (1.0f - b), w10 = a * (1.0f - b), w01 = (1.0f - a) * b, w11 = a * b;
+	return mk(((w00 * T00.x + w10 * T10.x) + w01 * T01.x) + w11 * T11.x,
+	          ((w00 * T00.y + w10 * T10.y) + w01 * T01.y) + w11 * T11.y,
+	          ((w00 * T00.z + w10 * T10.z) + w01 * T01.z) + w11 * T11.z);
+}
+
+// render.cl:380-394
+__device__ __forceinline__ f3 sky_box(const TraceParams &p, f3 dir) {
+	f3 sun_dir = ld3(p.sd.sun_direction);
+	float lobe = dm_powf(dm_max(dot3(dir, neg(sun_dir)), 0.0f), p.sd.sun_focus);
+	f3 sun = (ld3(p.sd.sun_color) * lobe) * p.sd.sun_intensity;
+	float u = dm_atan2pif(dir.z, dir.x) * 0.5f + 0.5f;
+	float v = dir.y * 0.5f + 0.5f;
+	return sample_sky(p.sky, p.sky_w, p.sky_h, u, v) + sun;
+}
+
+} // namespace
+
+// ---------------------------------------------------------------------------------
+// Trace kernel. 64-thread workgroups = one wave = one 8x8 pixel tile.
+// ---------------------------------------------------------------------------------
+template <bool COUNT_TRIS>
+__global__ __launch_bounds__(64) void srt_trace_kernel(const TraceParams p) {
+	const int width = p.rd.width;
+	const int tiles_x = (width + 7) >> 3;
+	const int tile = blockIdx.x;
+	const int lane = threadIdx.x;
+	const int px = (tile % tiles_x) * 8 + (lane & 7);
+	const int lrow = (tile / tiles_x) * 8 + (lane >> 3);
+	const bool valid = px < width && lrow < p.owned_rows;
+	const int py = global_row(lrow, p.rank, p.world, p.rows_per_block);
+	const uint32_t id = (uint32_t)px + (uint32_t)py * (uint32_t)width; // render.cl:488
+
+	const int ns = p.rd.num_samples;
+	const int nb = p.rd.num_bounces;
+	const int n_shapes = p.sd.num_shapes;
+	const LoopShape *__restrict__ loop_shapes = p.loop_shapes;
+	const float *__restrict__ wtris = p.wtris;
+
+	f3 sum = mk(0.f, 0.f, 0.f);
+	f3 org = mk(0.f, 0.f, 0.f), dir = mk(0.f, 0.f, 0.f), mask = mk(1.f, 1.f, 1.f), color = mk(0.f, 0.f, 0.f);
+	uint32_t seed = 0;
+	int sample = 0, bounce = 0;
+	bool fresh = true;
+	bool alive = valid && ns > 0 && nb > 0;
+	uint32_t n_rays = 0, n_sky = 0, n_tri = 0, n_tri_u = 0;
+
+	// A path with num_bounces <= 0 never enters the bounce loop (render.cl:403): colour 0.
+	while (__any(alive)) {
+		if (alive) {
+			if (fresh) {
+				// ---- new camera path (render.cl:496-516) ----
+				seed = ((uint32_t)sample + id * (uint32_t)ns) * p.rd.time * 5304u;
+				float ndc_x = ((float)px + random_float(seed)) / (float)width;
+				float ndc_y = ((float)py + random_float(seed)) / (float)p.rd.height;
+				float sx = ((2.f * ndc_x - 1.f) * p.rd.aspect_ratio) * p.rd.fov_scale;
+				float sy = (1.f - 2.f * ndc_y) * p.rd.fov_scale;
+				org = mk(p.rd.camera_to_world[3].x, p.rd.camera_to_world[3].y, p.rd.camera_to_world[3].z);
+				dir = normalize3(mat_by_vec(p.rd.camera_to_world, mk(sx, sy, -1.0f), 0.0f));
+				mask = mk(1.f, 1.f, 1.f);
+				color = mk(0.f, 0.f, 0.f);
+				bounce = 0;
+				fresh = false;
+			}
+
+			// ---- closest_intersection (render.cl:293-378), winner deferred ----
+			n_rays++;
+			float tmin = DM_INF_F;
+			int best = -1;
+			uint32_t best_tri = 0;
+			f3 inv = mk(0.f, 0.f, 0.f);
+			if (p.num_models > 0) inv = mk(1.0f / dir.x, 1.0f / dir.y, 1.0f / dir.z);
+
+			for (int i = 0; i < n_shapes; i++) {
+				const LoopShape &s = loop_shapes[i];
+				if (s.type == SRT_SHAPE_SPHERE) {
+					// render.cl:180-204
+					f3 L = mk(s.f[0] - org.x, s.f[1] - org.y, s.f[2] - org.z);
+					float b = dot3(L, dir);
+					float c = dot3(L, L) - s.f[3];
+					float disc = b * b - c;
+					float sq = dm_sqrtf(disc);
+					float t = b - sq;
+					if (t < 0.0f) t = b + sq;
+					bool hit = !(disc < 0.0f) && !(t < 0.0f);
+					if (hit && t < tmin) {
+						tmin = t;
+						best = i;
+					}
+				} else if (s.type == SRT_SHAPE_MODEL) {
+					// render.cl:279-290, tmax = current closest t
+					float t0 = 0.0f, t1 = tmin;
+					{
+						float a1 = (s.f[0] - org.x) * inv.x, a2 = (s.f[3] - org.x) * inv.x;
+						t0 = dm_max(t0, dm_min(a1, a2));
+						t1 = dm_min(t1, dm_max(a1, a2));
+						a1 = (s.f[1] - org.y) * inv.y, a2 = (s.f[4] - org.y) * inv.y;
+						t0 = dm_max(t0, dm_min(a1, a2));
+						t1 = dm_min(t1, dm_max(a1, a2));
+						a1 = (s.f[2] - org.z) * inv.z, a2 = (s.f[5] - org.z) * inv.z;
+						t0 = dm_max(t0, dm_min(a1, a2));
+						t1 = dm_min(t1, dm_max(a1, a2));
+					}
+					if (t0 < t1) {
+						const uint32_t first = s.a, count = s.b;
+						if (COUNT_TRIS) n_tri += count;
+						for (uint32_t j = 0; j < count; j++) {
+							// Moller-Trumbore (render.cl:243-275) on the pre-pass triangle
+							const float *__restrict__ w = wtris + (size_t)(first + j) * SRT_WTRI_FLOATS;
+							f3 v0 = mk(w[0], w[1], w[2]);
+							f3 e1 = mk(w[3], w[4], w[5]);
+							f3 e2 = mk(w[6], w[7], w[8]);
+							f3 h = cross3(dir, e2);
+							float a = dot3(e1, h);
+							float f = 1.0f / a;
+							f3 sv = org - v0;
+							float u = f * dot3(sv, h);
+							bool ok = !(a == 0.0f) && !(u < 0.0f || u > 1.0f);
+							if (COUNT_TRIS) n_tri_u += ok ? 1u : 0u;
+							f3 q = cross3(sv, e1);
+							float v = f * dot3(dir, q);
+							ok = ok && !(v < 0.0f || u + v > 1.0f);
+							float t = f * dot3(e2, q);
+							ok = ok && t > 0.0f;
+							if (ok && t < tmin) {
+								tmin = t;
+								best = i;
+								best_tri = j;
+							}
+						}
+					}
+				} else if (s.type == SRT_SHAPE_PLANE) {
+					// render.cl:206-221
+					f3 n = mk(s.f[3], s.f[4], s.f[5]);
+					float denom = dot3(n, dir);
+					float t = dot3(n, mk(s.f[0] - org.x, s.f[1] - org.y, s.f[2] - org.z)) / denom;
+					bool hit = !(dm_fabs(denom) == 0.0f) && !(t < 0.0f);
+					if (hit && t < tmin) {
+						tmin = t;
+						best = i;
+					}
+				}
+			}
+
+			// ---- winner: position, normal, material (render.cl:311-312,337-343,361-362,372-375) ----
+			int material_index = -1;
+			f3 pos = org, nrm = mk(0.f, 0.f, 0.f);
+			bool front = false;
+			if (best >= 0) {
+				const srt_shape *__restrict__ sh = p.shapes + best;
+				material_index = sh->material;
+				int type = sh->type;
+				pos = org + dir * tmin;
+				if (type == SRT_SHAPE_SPHERE) {
+					nrm = (pos - ld3(sh->shape.sphere.position)) / sh->shape.sphere.radius;
+				} else if (type == SRT_SHAPE_PLANE) {
+					nrm = ld3(sh->shape.plane.normal);
+				} else {
+					const srt_model *__restrict__ m = &sh->shape.model;
+					const float *__restrict__ w = wtris + (size_t)(loop_shapes[best].a + best_tri) * SRT_WTRI_FLOATS;
+					f3 v0 = mk(w[0], w[1], w[2]);
+					f3 e1 = mk(w[3], w[4], w[5]);
+					f3 e2 = mk(w[6], w[7], w[8]);
+					// barycentric_weights (render.cl:223-241), "shifted" (w2, w0, w1)
+					f3 v2 = pos - v0;
+					float d00 = dot3(e1, e1), d01 = dot3(e1, e2), d11 = dot3(e2, e2);
+					float d20 = dot3(v2, e1), d21 = dot3(v2, e2);
+					float den = d00 * d11 - d01 * d01;
+					float w0 = (d11 * d20 - d01 * d21) / den;
+					float w1 = (d00 * d21 - d01 * d20) / den;
+					float w2 = 1.0f - w0 - w1;
+					const srt_triangle *__restrict__ tr = p.triangles + (m->triangle_index + best_tri);
+					f3 n = (ld3(tr->vertices[0].normal) * w2 + ld3(tr->vertices[1].normal) * w0) + ld3(tr->vertices[2].normal) * w1;
+					n = mat_by_vec(m->transform, n, 0.0f); // forward matrix, as the reference
+					nrm = normalize3(n);
+				}
+				front = dot3(nrm, dir) < 0.0f;
+				nrm = nrm * (front ? 1.0f : -1.0f);
+			}
+
+			bool done;
+			if (material_index >= 0) {
+				if (p.rd.show_normals) {
+					color = mk(nrm.x * 0.5f + 0.5f, nrm.y * 0.5f + 0.5f, nrm.z * 0.5f + 0.5f); // render.cl:407-410
+					done = true;
+				} else {
+					const srt_material *__restrict__ mat = p.materials + material_index;
+					const float4 m0 = *reinterpret_cast<const float4 *>(&mat->smoothness);
+					const float2 m1 = *reinterpret_cast<const float2 *>(&mat->transmittance);
+					const float4 mc = *reinterpret_cast<const float4 *>(&mat->color);
+					const float4 me = *reinterpret_cast<const float4 *>(&mat->emission);
+					const float smoothness = m0.x, metallic = m0.y, specular = m0.z, emission_strength = m0.w;
+					const float transmittance = m1.x, ior = m1.y;
+					const f3 mcolor = mk(mc.x, mc.y, mc.z);
+					color = color + (mask * mk(me.x, me.y, me.z)) * emission_strength; // render.cl:413
+					done = (bounce == nb - 1);                                          // render.cl:415-416
+					if (!done) {
+						org = pos;
+						// cosine weighted direction: 6 draws (render.cl:421, 156-163)
+						float gx = random_normal(seed);
+						float gy = random_normal(seed);
+						float gz = random_normal(seed);
+						f3 rd_ = normalize3(mk(gx, gy, gz));
+						f3 hemi = rd_ * dm_sign(dot3(nrm, rd_));
+						f3 random_dir = normalize3(nrm + hemi);
+						f3 reflected_dir = reflect3(dir, nrm);
+						bool is_metallic = metallic > random_float(seed);
+						bool is_specular = specular > random_float(seed);
+						f3 rough_dir = mix3(random_dir, reflected_dir, smoothness);
+						bool is_transparent = transmittance > random_float(seed);
+						if (!is_transparent) {
+							dir = mix3(random_dir, rough_dir, (is_metallic || is_specular) ? 1.0f : 0.0f);
+							mask = mask * mix3(mcolor, mk(1.0f, 1.0f, 1.0f), is_specular ? 1.0f : 0.0f);
+						} else {
+							f3 in_dir = reflect3(rough_dir, nrm);
+							float mu = front ? 1.0f / ior : ior;
+							float cos_theta = dm_min(1.0f, dot3(in_dir, neg(nrm)));
+							float sin_theta = dm_sqrtf(1.0f - cos_theta * cos_theta);
+							bool reflected = mu * sin_theta > 1.0f;
+							if (!reflected) reflected = schlick(mu, cos_theta) > random_float(seed); // short-circuit ||
+							if (reflected) {
+								dir = rough_dir;
+							} else {
+								f3 out_perp = (in_dir + nrm * cos_theta) * mu;
+								float lsq = (out_perp.x * out_perp.x + out_perp.y * out_perp.y) + out_perp.z * out_perp.z;
+								f3 out_parallel = nrm * (-dm_sqrtf(dm_fabs(1.0f - lsq)));
+								dir = out_perp + out_parallel;
+								mask = mask * mcolor;
+							}
+						}
+						dir = normalize3(dir);
+						org = org + (nrm * dm_sign(dot3(nrm, dir))) * 0.001f; // render.cl:462
+						bounce++;
+					}
+				}
+			} else {
+				// miss: sky (render.cl:463-467)
+				n_sky++;
+				mask = mask * sky_box(p, dir);
+				color = color + mask;
+				done = true;
+			}
+
+			if (done) {
+				sum = sum + color; // serial, in sample order (render.cl:518)
+				sample++;
+				fresh = true;
+				alive = sample < ns;
+			}
+		}
+	}
+
+	if (valid) {
+		f3 c = sum / (float)ns; // render.cl:520 (ns == 0 -> 0/0 = NaN, as the reference)
+		float4 *out = reinterpret_cast<float4 *>(p.canvas) + ((size_t)lrow * width + px);
+		float4 o = *out;
+		o.x += c.x;
+		o.y += c.y;
+		o.z += c.z;
+		*out = o; // render.cl:522
+		if (c.x != c.x || c.y != c.y || c.z != c.z) atomicAdd(&p.counters[SRT_CTR_NAN], 1ull);
+	}
+
+	// one atomic per wave and counter
+	unsigned long long r = n_rays, k = n_sky, t3 = n_tri, t4 = n_tri_u;
+	unsigned long long np = valid ? (unsigned long long)(ns > 0 ? ns : 0) : 0ull;
+	for (int off = 32; off > 0; off >>= 1) {
+		r += __shfl_down(r, off);
+		k += __shfl_down(k, off);
+		np += __shfl_down(np, off);
+		if (COUNT_TRIS) {
+			t3 += __shfl_down(t3, off);
+			t4 += __shfl_down(t4, off);
+		}
+	}
+	if (lane == 0) {
+		atomicAdd(&p.counters[SRT_CTR_RAYS], r);
+		atomicAdd(&p.counters[SRT_CTR_SKY], k);
+		atomicAdd(&p.counters[SRT_CTR_PATHS], np);
+		if (COUNT_TRIS) {
+			atomicAdd(&p.counters[SRT_CTR_TRI], t3);
+			atomicAdd(&p.counters[SRT_CTR_TRI_PASS_U], t4);
+		}
+	}
+}
+
+// ---------------------------------------------------------------------------------
+// Pre-pass: world-space triangles per model instance. blockIdx.y = shape.
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void srt_prepass_kernel(const PrepassParams p) {
+	const int si = blockIdx.y;
+	if (si >= p.num_shapes) return;
+	const srt_shape *sh = p.shapes + si;
+	if (sh->type != SRT_SHAPE_MODEL) return;
+	const srt_model *m = &sh->shape.model;
+	const uint32_t n = m->num_triangles;
+	const uint32_t base = p.wtri_offset[si];
+	for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += gridDim.x * blockDim.x) {
+		const srt_triangle *t = p.triangles + (m->triangle_index + j);
+		// render.cl:325-328 then :247-248
+		f3 p0 = mat_by_vec(m->transform, ld3(t->vertices[0].pos), 1.0f);
+		f3 p1 = mat_by_vec(m->transform, ld3(t->vertices[1].pos), 1.0f);
+		f3 p2 = mat_by_vec(m->transform, ld3(t->vertices[2].pos), 1.0f);
+		f3 e1 = p1 - p0, e2 = p2 - p0;
+		float *w = p.wtris + (size_t)(base + j) * SRT_WTRI_FLOATS;
+		w[0] = p0.x, w[1] = p0.y, w[2] = p0.z;
+		w[3] = e1.x, w[4] = e1.y, w[5] = e1.z;
+		w[6] = e2.x, w[7] = e2.y, w[8] = e2.z;
+	}
+}
+
+// ---------------------------------------------------------------------------------
+// Resolve: canvas / num_steps -> ACES -> sqrt -> A,R,G,B bytes (render.cl:473-481,525-535)
+// 16 B in, 4 B out per pixel; HBM-bound.
+// ---------------------------------------------------------------------------------
+namespace {
+__device__ __forceinline__ float aces1(float x) {
+	const float a = 2.51f, b = 0.03f, c = 2.43f, d = 0.59f, e = 0.14f;
+	return dm_clamp((x * (x * a + b)) / (x * (x * c + d) + e), 0.0f, 1.0f);
+}
+__device__ __forceinline__ uint32_t to_uchar(float v) { return (v == v) ? ((uint32_t)(int)v & 255u) : 0u; }
+} // namespace
+
+__global__ __launch_bounds__(256) void srt_resolve_kernel(const ResolveParams p) {
+	const float4 *__restrict__ canvas = reinterpret_cast<const float4 *>(p.canvas);
+	uint32_t *__restrict__ out = reinterpret_cast<uint32_t *>(p.argb);
+	const float n = (float)p.num_steps;
+	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < p.num_pixels; i += gridDim.x * blockDim.x) {
+		float4 c = canvas[i];
+		float r = dm_sqrtf(aces1(c.x / n));
+		float g = dm_sqrtf(aces1(c.y / n));
+		float b = dm_sqrtf(aces1(c.z / n));
+		// memory order A, R, G, B (little endian word)
+		out[i] = 255u | (to_uchar(r * 255.0f) << 8) | (to_uchar(g * 255.0f) << 16) | (to_uchar(b * 255.0f) << 24);
+	}
+}
+
+// ---------------------------------------------------------------------------------
+// launch wrappers (host)
+// ---------------------------------------------------------------------------------
+void srt_launch_trace(const TraceParams &p, bool count_triangles, void *stream) {
+	const int tiles_x = (p.rd.width + 7) / 8, tiles_y = (p.owned_rows + 7) / 8;
+	const long long tiles = (long long)tiles_x * tiles_y;
+	if (tiles <= 0) return;
+	dim3 grid((unsigned)tiles), block(64);
+	if (count_triangles)
+		hipLaunchKernelGGL(srt_trace_kernel<true>, grid, block, 0, (hipStream_t)stream, p);
+	else
+		hipLaunchKernelGGL(srt_trace_kernel<false>, grid, block, 0, (hipStream_t)stream, p);
+}
+
+void srt_launch_prepass(const PrepassParams &p, uint64_t max_tris_per_model, void *stream) {
+	if (p.num_shapes <= 0 || max_tris_per_model == 0) return;
+	unsigned gx = (unsigned)((max_tris_per_model + 255) / 256);
+	if (gx > 4096) gx = 4096;
+	dim3 grid(gx, (unsigned)p.num_shapes), block(256);
+	hipLaunchKernelGGL(srt_prepass_kernel, grid, block, 0, (hipStream_t)stream, p);
+}
+
+void srt_launch_resolve(const ResolveParams &p, void *stream) {
+	if (p.num_pixels == 0) return;
+	unsigned gx = (p.num_pixels + 255) / 256;
+	if (gx > 4096) gx = 4096;
+	hipLaunchKernelGGL(srt_resolve_kernel, dim3(gx), dim3(256), 0, (hipStream_t)stream, p);
+}

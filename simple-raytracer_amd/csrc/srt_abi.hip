@@ -1,0 +1,523 @@
+// srt_abi.hip — host side of libsrt_hip.so: the C ABI of include/srt_abi.h over the
+// kernels in kernels.hip. This is what replaces the boost.compute/OpenCL dispatch of
+// the reference's Tracer (/root/reference/src/tracer.cpp:11-116). HIP runtime only.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/srt_abi.h"
+#include "device_types.h"
+
+namespace {
+
+thread_local std::string g_create_error;
+
+template <class T>
+struct DevBuf {
+	T *ptr = nullptr;
+	size_t cap = 0; // elements
+	// "buffers only ever grow" (src/tracer.cpp:5-9)
+	hipError_t reserve(size_t n) {
+		if (n < 1) n = 1;
+		if (n <= cap) return hipSuccess;
+		if (ptr) (void)hipFree(ptr);
+		ptr = nullptr;
+		cap = 0;
+		hipError_t e = hipMalloc(reinterpret_cast<void **>(&ptr), n * sizeof(T));
+		if (e == hipSuccess) cap = n;
+		return e;
+	}
+	void release() {
+		if (ptr) (void)hipFree(ptr);
+		ptr = nullptr;
+		cap = 0;
+	}
+};
+
+} // namespace
+
+struct srt_tracer {
+	int width = 0, height = 0, device = 0;
+	hipStream_t own_stream = nullptr, stream = nullptr;
+	DevBuf<float> canvas_own;
+	float *canvas = nullptr;
+	size_t canvas_bytes = 0; // of the buffer in use
+	DevBuf<uint8_t> argb;
+	DevBuf<srt_shape> shapes;
+	DevBuf<LoopShape> loop_shapes;
+	DevBuf<srt_triangle> triangles;
+	DevBuf<srt_material> materials;
+	DevBuf<float> wtris;
+	DevBuf<uint32_t> wtri_offset;
+	DevBuf<float> sky;
+	DevBuf<unsigned long long> counters;
+	int sky_w = 0, sky_h = 0;
+	srt_scene_data sd{};
+	int num_models = 0;
+	bool scene_set = false;
+	bool count_tris = false;
+	int rank = 0, world = 1, rows_per_block = 8, owned_rows = 0;
+	hipEvent_t ev_t0 = nullptr, ev_t1 = nullptr, ev_r0 = nullptr, ev_r1 = nullptr;
+	bool have_trace_ev = false, have_resolve_ev = false;
+	std::string err;
+};
+
+namespace {
+
+int fail(srt_tracer *t, int code, const std::string &msg) {
+	if (t) t->err = msg;
+	else g_create_error = msg;
+	return code;
+}
+
+#define SRT_HIP(t, call)                                                                              \
+	do {                                                                                              \
+		hipError_t e_ = (call);                                                                       \
+		if (e_ != hipSuccess)                                                                         \
+			return fail((t), SRT_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_));         \
+	} while (0)
+
+int num_blocks(int height, int rpb) { return (height + rpb - 1) / rpb; }
+
+size_t owned_pixels(const srt_tracer *t) { return (size_t)t->owned_rows * (size_t)t->width; }
+
+int clear_canvas_impl(srt_tracer *t) {
+	// enqueue_fill_buffer with 0.0f over the whole canvas (src/tracer.cpp:98-101)
+	SRT_HIP(t, hipMemsetAsync(t->canvas, 0, t->canvas_bytes, t->stream));
+	return SRT_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+const char *srt_version(void) { return "srt-hip 0.1 gfx950 parity (fp-contract=off, IEEE div/sqrt, detmath)"; }
+
+const char *srt_last_error(const srt_tracer *t) { return t ? t->err.c_str() : g_create_error.c_str(); }
+
+int srt_partition_owned_rows(int height, int rank, int world, int rpb) {
+	if (height < 0 || world < 1 || rank < 0 || rank >= world || rpb < 1) return -1;
+	int rows = 0;
+	const int nb = num_blocks(height, rpb);
+	for (int b = rank; b < nb; b += world) {
+		int r = height - b * rpb;
+		rows += r < rpb ? r : rpb;
+	}
+	return rows;
+}
+
+int srt_partition_padded_rows(int height, int world, int rpb) {
+	if (height < 0 || world < 1 || rpb < 1) return -1;
+	const int nb = num_blocks(height, rpb);
+	return ((nb + world - 1) / world) * rpb;
+}
+
+int srt_partition_global_row(int height, int rank, int world, int rpb, int local_row) {
+	if (height < 0 || world < 1 || rank < 0 || rank >= world || rpb < 1 || local_row < 0) return -1;
+	const int lb = local_row / rpb;
+	const int y = (lb * world + rank) * rpb + (local_row - lb * rpb);
+	return y < height ? y : -1;
+}
+
+int srt_partition_unpermute(const void *gathered, void *image, int height, int world, int rpb, size_t row_bytes) {
+	if (!gathered || !image || height < 0 || world < 1 || rpb < 1) return SRT_ERR_INVALID;
+	const int padded = srt_partition_padded_rows(height, world, rpb);
+	const char *src = static_cast<const char *>(gathered);
+	char *dst = static_cast<char *>(image);
+	for (int r = 0; r < world; r++) {
+		for (int lr = 0; lr < padded; lr++) {
+			const int y = srt_partition_global_row(height, r, world, rpb, lr);
+			if (y < 0) continue;
+			memcpy(dst + (size_t)y * row_bytes, src + ((size_t)r * padded + lr) * row_bytes, row_bytes);
+		}
+	}
+	return SRT_OK;
+}
+
+int srt_create(int width, int height, int device_index, srt_tracer **out) {
+	if (!out) return fail(nullptr, SRT_ERR_INVALID, "srt_create: out is NULL");
+	*out = nullptr;
+	if (width <= 0 || height <= 0) return fail(nullptr, SRT_ERR_INVALID, "srt_create: width and height must be positive");
+	int ndev = 0;
+	hipError_t e = hipGetDeviceCount(&ndev);
+	if (e != hipSuccess || ndev <= 0)
+		return fail(nullptr, SRT_ERR_HIP, std::string("srt_create: no HIP device (") + hipGetErrorString(e) + ")");
+	if (device_index < 0 || device_index >= ndev) return fail(nullptr, SRT_ERR_INVALID, "srt_create: device_index out of range");
+	srt_tracer *t = new (std::nothrow) srt_tracer();
+	if (!t) return fail(nullptr, SRT_ERR_INVALID, "srt_create: out of host memory");
+	t->width = width;
+	t->height = height;
+	t->device = device_index;
+	t->owned_rows = height;
+	auto bail = [&](const char *what, hipError_t err) {
+		std::string m = std::string("srt_create: ") + what + ": " + hipGetErrorString(err);
+		srt_destroy(t);
+		return fail(nullptr, SRT_ERR_HIP, m);
+	};
+	if ((e = hipSetDevice(device_index)) != hipSuccess) return bail("hipSetDevice", e);
+	if ((e = hipStreamCreateWithFlags(&t->own_stream, hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate", e);
+	t->stream = t->own_stream;
+	const size_t px = (size_t)width * height;
+	if ((e = t->canvas_own.reserve(px * 4)) != hipSuccess) return bail("canvas alloc", e);
+	t->canvas = t->canvas_own.ptr;
+	t->canvas_bytes = px * 16;
+	if ((e = t->argb.reserve(px * 4)) != hipSuccess) return bail("argb alloc", e);
+	if ((e = t->counters.reserve(SRT_CTR_COUNT)) != hipSuccess) return bail("counter alloc", e);
+	if ((e = t->shapes.reserve(1)) != hipSuccess || (e = t->loop_shapes.reserve(1)) != hipSuccess ||
+	    (e = t->triangles.reserve(1)) != hipSuccess || (e = t->materials.reserve(1)) != hipSuccess ||
+	    (e = t->wtris.reserve(SRT_WTRI_FLOATS)) != hipSuccess || (e = t->wtri_offset.reserve(1)) != hipSuccess)
+		return bail("scene alloc", e);
+	if ((e = hipEventCreate(&t->ev_t0)) != hipSuccess || (e = hipEventCreate(&t->ev_t1)) != hipSuccess ||
+	    (e = hipEventCreate(&t->ev_r0)) != hipSuccess || (e = hipEventCreate(&t->ev_r1)) != hipSuccess)
+		return bail("hipEventCreate", e);
+	if ((e = hipMemsetAsync(t->canvas, 0, t->canvas_bytes, t->stream)) != hipSuccess) return bail("canvas clear", e);
+	if ((e = hipMemsetAsync(t->counters.ptr, 0, SRT_CTR_COUNT * sizeof(unsigned long long), t->stream)) != hipSuccess)
+		return bail("counter clear", e);
+	if ((e = hipStreamSynchronize(t->stream)) != hipSuccess) return bail("sync", e);
+	*out = t;
+	return SRT_OK;
+}
+
+void srt_destroy(srt_tracer *t) {
+	if (!t) return;
+	(void)hipSetDevice(t->device);
+	if (t->own_stream) (void)hipStreamSynchronize(t->own_stream);
+	t->canvas_own.release();
+	t->argb.release();
+	t->shapes.release();
+	t->loop_shapes.release();
+	t->triangles.release();
+	t->materials.release();
+	t->wtris.release();
+	t->wtri_offset.release();
+	t->sky.release();
+	t->counters.release();
+	if (t->ev_t0) (void)hipEventDestroy(t->ev_t0);
+	if (t->ev_t1) (void)hipEventDestroy(t->ev_t1);
+	if (t->ev_r0) (void)hipEventDestroy(t->ev_r0);
+	if (t->ev_r1) (void)hipEventDestroy(t->ev_r1);
+	if (t->own_stream) (void)hipStreamDestroy(t->own_stream);
+	delete t;
+}
+
+int srt_set_skybox(srt_tracer *t, const float *rgba, int width, int height) {
+	if (!t) return SRT_ERR_INVALID;
+	if (!rgba || width <= 0 || height <= 0) return fail(t, SRT_ERR_INVALID, "srt_set_skybox: bad image");
+	SRT_HIP(t, hipSetDevice(t->device));
+	const size_t n = (size_t)width * height * 4;
+	SRT_HIP(t, hipStreamSynchronize(t->stream)); // kernels may still read the old image
+	SRT_HIP(t, t->sky.reserve(n));
+	SRT_HIP(t, hipMemcpyAsync(t->sky.ptr, rgba, n * sizeof(float), hipMemcpyHostToDevice, t->stream));
+	SRT_HIP(t, hipStreamSynchronize(t->stream));
+	t->sky_w = width;
+	t->sky_h = height;
+	return SRT_OK;
+}
+
+int srt_update_scene(srt_tracer *t, const srt_shape *shapes, size_t n_shapes, const srt_triangle *triangles,
+                     size_t n_triangles, const srt_material *materials, size_t n_materials,
+                     const srt_scene_data *scene) {
+	if (!t) return SRT_ERR_INVALID;
+	if (!scene) return fail(t, SRT_ERR_INVALID, "srt_update_scene: scene is NULL");
+	if ((n_shapes && !shapes) || (n_triangles && !triangles) || (n_materials && !materials))
+		return fail(t, SRT_ERR_INVALID, "srt_update_scene: NULL array with non-zero count");
+	if (n_shapes > 0x7fffffffu || n_triangles > 0xffffffffu) return fail(t, SRT_ERR_INVALID, "srt_update_scene: too many records");
+
+	// Host pass: loop records + world-triangle offsets. The reference would read out of
+	// bounds for a bad triangle range or material index; we refuse instead.
+	std::vector<LoopShape> loop(n_shapes ? n_shapes : 1);
+	std::vector<uint32_t> offs(n_shapes ? n_shapes : 1, 0u);
+	uint64_t total_wtris = 0, max_tris = 0;
+	int num_models = 0;
+	for (size_t i = 0; i < n_shapes; i++) {
+		const srt_shape &s = shapes[i];
+		LoopShape &l = loop[i];
+		memset(&l, 0, sizeof l);
+		l.type = s.type;
+		if (s.material >= 0 && (size_t)s.material >= n_materials) {
+			char buf[128];
+			snprintf(buf, sizeof buf, "srt_update_scene: shape %zu uses material %d but only %zu exist", i, s.material, n_materials);
+			return fail(t, SRT_ERR_INVALID, buf);
+		}
+		if (s.type == SRT_SHAPE_SPHERE) {
+			l.f[0] = s.shape.sphere.position.x;
+			l.f[1] = s.shape.sphere.position.y;
+			l.f[2] = s.shape.sphere.position.z;
+			l.f[3] = s.shape.sphere.radius * s.shape.sphere.radius; // render.cl:187
+		} else if (s.type == SRT_SHAPE_PLANE) {
+			l.f[0] = s.shape.plane.position.x;
+			l.f[1] = s.shape.plane.position.y;
+			l.f[2] = s.shape.plane.position.z;
+			l.f[3] = s.shape.plane.normal.x;
+			l.f[4] = s.shape.plane.normal.y;
+			l.f[5] = s.shape.plane.normal.z;
+		} else if (s.type == SRT_SHAPE_MODEL) {
+			const srt_model &m = s.shape.model;
+			if ((uint64_t)m.triangle_index + m.num_triangles > n_triangles) {
+				char buf[160];
+				snprintf(buf, sizeof buf, "srt_update_scene: shape %zu references triangles [%u, %u+%u) but only %zu exist", i,
+				         m.triangle_index, m.triangle_index, m.num_triangles, n_triangles);
+				return fail(t, SRT_ERR_INVALID, buf);
+			}
+			l.f[0] = m.bounding_min.x;
+			l.f[1] = m.bounding_min.y;
+			l.f[2] = m.bounding_min.z;
+			l.f[3] = m.bounding_max.x;
+			l.f[4] = m.bounding_max.y;
+			l.f[5] = m.bounding_max.z;
+			if (total_wtris + m.num_triangles > 0xffffffffull) return fail(t, SRT_ERR_INVALID, "srt_update_scene: too many world triangles");
+			l.a = (uint32_t)total_wtris;
+			l.b = m.num_triangles;
+			offs[i] = (uint32_t)total_wtris;
+			total_wtris += m.num_triangles;
+			if (m.num_triangles > max_tris) max_tris = m.num_triangles;
+			num_models++;
+		}
+	}
+
+	SRT_HIP(t, hipSetDevice(t->device));
+	SRT_HIP(t, hipStreamSynchronize(t->stream)); // previous launches may still read the old scene
+	SRT_HIP(t, t->shapes.reserve(n_shapes));
+	SRT_HIP(t, t->loop_shapes.reserve(n_shapes));
+	SRT_HIP(t, t->wtri_offset.reserve(n_shapes));
+	SRT_HIP(t, t->triangles.reserve(n_triangles));
+	SRT_HIP(t, t->materials.reserve(n_materials));
+	SRT_HIP(t, t->wtris.reserve((size_t)total_wtris * SRT_WTRI_FLOATS + SRT_WTRI_FLOATS));
+	if (n_shapes) {
+		SRT_HIP(t, hipMemcpyAsync(t->shapes.ptr, shapes, n_shapes * sizeof(srt_shape), hipMemcpyHostToDevice, t->stream));
+		SRT_HIP(t, hipMemcpyAsync(t->loop_shapes.ptr, loop.data(), n_shapes * sizeof(LoopShape), hipMemcpyHostToDevice, t->stream));
+		SRT_HIP(t, hipMemcpyAsync(t->wtri_offset.ptr, offs.data(), n_shapes * sizeof(uint32_t), hipMemcpyHostToDevice, t->stream));
+	}
+	if (n_triangles)
+		SRT_HIP(t, hipMemcpyAsync(t->triangles.ptr, triangles, n_triangles * sizeof(srt_triangle), hipMemcpyHostToDevice, t->stream));
+	if (n_materials)
+		SRT_HIP(t, hipMemcpyAsync(t->materials.ptr, materials, n_materials * sizeof(srt_material), hipMemcpyHostToDevice, t->stream));
+
+	if (num_models > 0 && total_wtris > 0) {
+		// blockIdx.y = shape index; launch in slabs of 65535 shapes
+		for (size_t base = 0; base < n_shapes; base += 65535) {
+			PrepassParams pp;
+			pp.shapes = t->shapes.ptr + base;
+			pp.triangles = t->triangles.ptr;
+			pp.wtri_offset = t->wtri_offset.ptr + base;
+			pp.wtris = t->wtris.ptr;
+			size_t cnt = n_shapes - base;
+			pp.num_shapes = (int32_t)(cnt > 65535 ? 65535 : cnt);
+			pp.num_triangles = (uint32_t)n_triangles;
+			srt_launch_prepass(pp, max_tris, t->stream);
+		}
+		SRT_HIP(t, hipGetLastError());
+	}
+	SRT_HIP(t, hipStreamSynchronize(t->stream)); // host arrays are free again on return
+
+	t->sd = *scene;
+	t->sd.num_shapes = (int32_t)n_shapes; // src/tracer.cpp:94
+	t->num_models = num_models;
+	t->scene_set = true;
+	return SRT_OK;
+}
+
+int srt_clear_canvas(srt_tracer *t) {
+	if (!t) return SRT_ERR_INVALID;
+	SRT_HIP(t, hipSetDevice(t->device));
+	return clear_canvas_impl(t);
+}
+
+int srt_trace(srt_tracer *t, const srt_render_data *options) {
+	if (!t) return SRT_ERR_INVALID;
+	if (!options) return fail(t, SRT_ERR_INVALID, "srt_trace: options is NULL");
+	if (options->width != t->width || options->height != t->height)
+		return fail(t, SRT_ERR_INVALID, "srt_trace: options width/height differ from the handle's (no resize, tracer.hpp:61-66)");
+	if (t->sky_w <= 0) return fail(t, SRT_ERR_STATE, "srt_trace: no skybox set (srt_set_skybox)");
+	SRT_HIP(t, hipSetDevice(t->device));
+	TraceParams p;
+	memset(&p, 0, sizeof p);
+	p.rd = *options;
+	if (t->scene_set) {
+		p.sd = t->sd;
+	} else {
+		memset(&p.sd, 0, sizeof p.sd); // kernel arg 1 never set: behave as the empty scene
+	}
+	p.loop_shapes = t->loop_shapes.ptr;
+	p.shapes = t->shapes.ptr;
+	p.triangles = t->triangles.ptr;
+	p.materials = t->materials.ptr;
+	p.wtris = t->wtris.ptr;
+	p.sky = t->sky.ptr;
+	p.canvas = t->canvas;
+	p.counters = t->counters.ptr;
+	p.sky_w = t->sky_w;
+	p.sky_h = t->sky_h;
+	p.num_models = t->num_models;
+	p.rank = t->rank;
+	p.world = t->world;
+	p.rows_per_block = t->rows_per_block;
+	p.owned_rows = t->owned_rows;
+	SRT_HIP(t, hipEventRecord(t->ev_t0, t->stream));
+	srt_launch_trace(p, t->count_tris, t->stream);
+	SRT_HIP(t, hipGetLastError());
+	SRT_HIP(t, hipEventRecord(t->ev_t1, t->stream));
+	t->have_trace_ev = true;
+	return SRT_OK;
+}
+
+int srt_resolve(srt_tracer *t, uint32_t ticks_stopped) {
+	if (!t) return SRT_ERR_INVALID;
+	SRT_HIP(t, hipSetDevice(t->device));
+	ResolveParams rp;
+	rp.canvas = t->canvas;
+	rp.argb = t->argb.ptr;
+	rp.num_steps = ticks_stopped;
+	rp.num_pixels = (uint32_t)owned_pixels(t);
+	SRT_HIP(t, hipEventRecord(t->ev_r0, t->stream));
+	srt_launch_resolve(rp, t->stream);
+	SRT_HIP(t, hipGetLastError());
+	SRT_HIP(t, hipEventRecord(t->ev_r1, t->stream));
+	t->have_resolve_ev = true;
+	return SRT_OK;
+}
+
+int srt_synchronize(srt_tracer *t) {
+	if (!t) return SRT_ERR_INVALID;
+	SRT_HIP(t, hipSetDevice(t->device));
+	SRT_HIP(t, hipStreamSynchronize(t->stream));
+	return SRT_OK;
+}
+
+int srt_render(srt_tracer *t, const srt_render_data *options, uint32_t ticks_stopped, uint8_t *argb_out) {
+	if (!t) return SRT_ERR_INVALID;
+	if (!argb_out) return fail(t, SRT_ERR_INVALID, "srt_render: argb_out is NULL");
+	int rc = srt_trace(t, options);
+	if (rc) return rc;
+	rc = srt_resolve(t, ticks_stopped);
+	if (rc) return rc;
+	// blocking read-back, as queue.enqueue_read_buffer (src/tracer.cpp:115)
+	SRT_HIP(t, hipMemcpyAsync(argb_out, t->argb.ptr, owned_pixels(t) * 4, hipMemcpyDeviceToHost, t->stream));
+	SRT_HIP(t, hipStreamSynchronize(t->stream));
+	return SRT_OK;
+}
+
+int srt_read_canvas(srt_tracer *t, float *rgba_out) {
+	if (!t) return SRT_ERR_INVALID;
+	if (!rgba_out) return fail(t, SRT_ERR_INVALID, "srt_read_canvas: NULL");
+	SRT_HIP(t, hipSetDevice(t->device));
+	SRT_HIP(t, hipMemcpyAsync(rgba_out, t->canvas, owned_pixels(t) * 16, hipMemcpyDeviceToHost, t->stream));
+	SRT_HIP(t, hipStreamSynchronize(t->stream));
+	return SRT_OK;
+}
+
+int srt_read_argb(srt_tracer *t, uint8_t *argb_out) {
+	if (!t) return SRT_ERR_INVALID;
+	if (!argb_out) return fail(t, SRT_ERR_INVALID, "srt_read_argb: NULL");
+	SRT_HIP(t, hipSetDevice(t->device));
+	SRT_HIP(t, hipMemcpyAsync(argb_out, t->argb.ptr, owned_pixels(t) * 4, hipMemcpyDeviceToHost, t->stream));
+	SRT_HIP(t, hipStreamSynchronize(t->stream));
+	return SRT_OK;
+}
+
+int srt_get_counters(srt_tracer *t, srt_counters *out) {
+	if (!t) return SRT_ERR_INVALID;
+	if (!out) return fail(t, SRT_ERR_INVALID, "srt_get_counters: NULL");
+	SRT_HIP(t, hipSetDevice(t->device));
+	unsigned long long h[SRT_CTR_COUNT];
+	SRT_HIP(t, hipMemcpyAsync(h, t->counters.ptr, sizeof h, hipMemcpyDeviceToHost, t->stream));
+	SRT_HIP(t, hipStreamSynchronize(t->stream));
+	out->paths = h[SRT_CTR_PATHS];
+	out->rays = h[SRT_CTR_RAYS];
+	out->sky = h[SRT_CTR_SKY];
+	out->tri_tests = h[SRT_CTR_TRI];
+	out->tri_pass_u = h[SRT_CTR_TRI_PASS_U];
+	out->nan_pixels = h[SRT_CTR_NAN];
+	return SRT_OK;
+}
+
+int srt_reset_counters(srt_tracer *t) {
+	if (!t) return SRT_ERR_INVALID;
+	SRT_HIP(t, hipSetDevice(t->device));
+	SRT_HIP(t, hipMemsetAsync(t->counters.ptr, 0, SRT_CTR_COUNT * sizeof(unsigned long long), t->stream));
+	return SRT_OK;
+}
+
+int srt_last_kernel_ms(srt_tracer *t, float *trace_ms, float *resolve_ms) {
+	if (!t) return SRT_ERR_INVALID;
+	SRT_HIP(t, hipSetDevice(t->device));
+	SRT_HIP(t, hipStreamSynchronize(t->stream));
+	if (trace_ms) {
+		*trace_ms = 0.f;
+		if (t->have_trace_ev) SRT_HIP(t, hipEventElapsedTime(trace_ms, t->ev_t0, t->ev_t1));
+	}
+	if (resolve_ms) {
+		*resolve_ms = 0.f;
+		if (t->have_resolve_ev) SRT_HIP(t, hipEventElapsedTime(resolve_ms, t->ev_r0, t->ev_r1));
+	}
+	return SRT_OK;
+}
+
+int srt_device_buffers(srt_tracer *t, void **canvas, size_t *canvas_bytes, void **argb, size_t *argb_bytes) {
+	if (!t) return SRT_ERR_INVALID;
+	if (canvas) *canvas = t->canvas;
+	if (canvas_bytes) *canvas_bytes = t->canvas_bytes;
+	if (argb) *argb = t->argb.ptr;
+	if (argb_bytes) *argb_bytes = t->argb.cap;
+	return SRT_OK;
+}
+
+int srt_bind_canvas(srt_tracer *t, void *device_canvas, size_t bytes) {
+	if (!t) return SRT_ERR_INVALID;
+	SRT_HIP(t, hipSetDevice(t->device));
+	SRT_HIP(t, hipStreamSynchronize(t->stream));
+	if (!device_canvas) {
+		t->canvas = t->canvas_own.ptr;
+		t->canvas_bytes = t->canvas_own.cap * sizeof(float);
+		return SRT_OK;
+	}
+	if (bytes < owned_pixels(t) * 16) return fail(t, SRT_ERR_INVALID, "srt_bind_canvas: buffer smaller than owned_rows*width*16");
+	t->canvas = static_cast<float *>(device_canvas);
+	t->canvas_bytes = bytes;
+	return SRT_OK;
+}
+
+int srt_bind_stream(srt_tracer *t, void *hip_stream) {
+	if (!t) return SRT_ERR_INVALID;
+	SRT_HIP(t, hipSetDevice(t->device));
+	SRT_HIP(t, hipStreamSynchronize(t->stream));
+	t->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : t->own_stream;
+	return SRT_OK;
+}
+
+int srt_set_partition(srt_tracer *t, int rank, int world, int rows_per_block) {
+	if (!t) return SRT_ERR_INVALID;
+	if (world < 1 || rank < 0 || rank >= world || rows_per_block < 1)
+		return fail(t, SRT_ERR_INVALID, "srt_set_partition: need 0 <= rank < world and rows_per_block >= 1");
+	SRT_HIP(t, hipSetDevice(t->device));
+	SRT_HIP(t, hipStreamSynchronize(t->stream));
+	const int padded = srt_partition_padded_rows(t->height, world, rows_per_block);
+	const size_t need = (size_t)padded * t->width * 4; // floats; padded >= owned
+	if (t->canvas == t->canvas_own.ptr) {
+		SRT_HIP(t, t->canvas_own.reserve(need));
+		t->canvas = t->canvas_own.ptr;
+		t->canvas_bytes = t->canvas_own.cap * sizeof(float);
+	} else if (t->canvas_bytes < need * sizeof(float)) {
+		return fail(t, SRT_ERR_INVALID, "srt_set_partition: bound canvas too small for padded_rows*width*16");
+	}
+	SRT_HIP(t, t->argb.reserve((size_t)padded * t->width * 4));
+	t->rank = rank;
+	t->world = world;
+	t->rows_per_block = rows_per_block;
+	t->owned_rows = srt_partition_owned_rows(t->height, rank, world, rows_per_block);
+	SRT_HIP(t, hipMemsetAsync(t->argb.ptr, 0, t->argb.cap, t->stream));
+	return clear_canvas_impl(t);
+}
+
+/* test hook: build with triangle counters (instrumented kernel variant) */
+int srt_set_count_triangles(srt_tracer *t, int enable) {
+	if (!t) return SRT_ERR_INVALID;
+	t->count_tris = enable != 0;
+	return SRT_OK;
+}
+
+} // extern "C"

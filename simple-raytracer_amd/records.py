@@ -86,7 +86,7 @@ def as_records(a, dtype):
     """Return `a` as a C-contiguous array of exactly `dtype` (the ABI layout)."""
     a = np.asarray(a)
     if a.dtype == dtype:
-        return np.ascontiguousarray(a)
+        return a if a.flags.c_contiguous else np.ascontiguousarray(a)
     if a.dtype.names is None and a.size == 0:
         return np.zeros(0, dtype)
     out = np.zeros(a.shape, dtype)

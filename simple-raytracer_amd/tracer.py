@@ -1,0 +1,222 @@
+"""ctypes binding of the C ABI (include/srt_abi.h) and a `Tracer` with the reference's
+class shape (/root/reference/include/tracer.hpp:26-88): ctor(width, height), public
+`options` / `scene_data`, update_scene(shapes, triangles, materials), clear_canvas(),
+render(ticks_stopped, output).
+
+There is NO CPU fallback here: if lib/libsrt_hip.so is missing or no GPU is present the
+calls raise. The oracle is never imported from this package.
+"""
+import ctypes as C
+from pathlib import Path
+
+import numpy as np
+
+from . import records as R
+
+PKG = Path(__file__).resolve().parent
+LIB_PATH = PKG / "lib" / "libsrt_hip.so"
+
+# every symbol include/srt_abi.h declares
+ABI_SYMBOLS = [
+    "srt_create", "srt_destroy", "srt_last_error", "srt_set_skybox", "srt_update_scene", "srt_clear_canvas",
+    "srt_render", "srt_trace", "srt_resolve", "srt_synchronize", "srt_read_canvas", "srt_read_argb",
+    "srt_get_counters", "srt_set_count_triangles", "srt_reset_counters", "srt_last_kernel_ms",
+    "srt_device_buffers", "srt_bind_canvas", "srt_bind_stream", "srt_set_partition",
+    "srt_partition_owned_rows", "srt_partition_padded_rows", "srt_partition_global_row",
+    "srt_partition_unpermute", "srt_version",
+]
+
+
+class Counters(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in ("paths", "rays", "sky", "tri_tests", "tri_pass_u", "nan_pixels")]
+
+    def as_dict(self):
+        return {n: int(getattr(self, n)) for n, _ in self._fields_}
+
+
+class SrtError(RuntimeError):
+    """Raised where the reference would throw a boost::compute exception."""
+
+
+_lib = None
+
+
+def load_library():
+    """dlopen lib/libsrt_hip.so. Fails loudly when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not LIB_PATH.exists():
+        raise SrtError(f"{LIB_PATH} not built: run `python __graft_entry__.py` / simple-raytracer_amd/build.py (needs hipcc)")
+    lib = C.CDLL(str(LIB_PATH))
+    vp, i, sz = C.c_void_p, C.c_int, C.c_size_t
+    lib.srt_create.argtypes = [i, i, i, C.POINTER(vp)]
+    lib.srt_destroy.argtypes = [vp]
+    lib.srt_destroy.restype = None
+    lib.srt_last_error.argtypes = [vp]
+    lib.srt_last_error.restype = C.c_char_p
+    lib.srt_set_skybox.argtypes = [vp, vp, i, i]
+    lib.srt_update_scene.argtypes = [vp, vp, sz, vp, sz, vp, sz, vp]
+    lib.srt_clear_canvas.argtypes = [vp]
+    lib.srt_render.argtypes = [vp, vp, C.c_uint32, vp]
+    lib.srt_trace.argtypes = [vp, vp]
+    lib.srt_resolve.argtypes = [vp, C.c_uint32]
+    lib.srt_synchronize.argtypes = [vp]
+    lib.srt_read_canvas.argtypes = [vp, vp]
+    lib.srt_read_argb.argtypes = [vp, vp]
+    lib.srt_get_counters.argtypes = [vp, C.POINTER(Counters)]
+    lib.srt_set_count_triangles.argtypes = [vp, i]
+    lib.srt_reset_counters.argtypes = [vp]
+    lib.srt_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    lib.srt_device_buffers.argtypes = [vp, C.POINTER(vp), C.POINTER(sz), C.POINTER(vp), C.POINTER(sz)]
+    lib.srt_bind_canvas.argtypes = [vp, vp, sz]
+    lib.srt_bind_stream.argtypes = [vp, vp]
+    lib.srt_set_partition.argtypes = [vp, i, i, i]
+    lib.srt_partition_owned_rows.argtypes = [i, i, i, i]
+    lib.srt_partition_padded_rows.argtypes = [i, i, i]
+    lib.srt_partition_global_row.argtypes = [i, i, i, i, i]
+    lib.srt_partition_unpermute.argtypes = [vp, vp, i, i, i, sz]
+    lib.srt_version.restype = C.c_char_p
+    _lib = lib
+    return lib
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class Tracer:
+    """Mirror of the reference's `class Tracer`. Field and method names are the
+    reference's; records are numpy scalars of records.RENDER_DATA / SCENE_DATA."""
+
+    def __init__(self, width, height, device=0):
+        self.lib = load_library()
+        self._h = C.c_void_p()
+        rc = self.lib.srt_create(width, height, device, C.byref(self._h))
+        if rc:
+            raise SrtError(self.lib.srt_last_error(None).decode())
+        self.width, self.height = width, height
+        # RenderData(width, height): num_samples = 4, num_bounces = 10 (tracer.hpp:61-66)
+        self.options = R.render_data(width, height, num_samples=4, num_bounces=10)
+        self.scene_data = R.scene_data(0)
+        self.owned_rows = height
+
+    # -- plumbing --
+    def _check(self, rc):
+        if rc:
+            raise SrtError(self.lib.srt_last_error(self._h).decode())
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self.lib.srt_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- the reference's interface --
+    def set_skybox(self, rgba):
+        rgba = np.ascontiguousarray(rgba, np.float32)
+        assert rgba.ndim == 3 and rgba.shape[2] == 4
+        self._check(self.lib.srt_set_skybox(self._h, _ptr(rgba), rgba.shape[1], rgba.shape[0]))
+
+    def update_scene(self, shapes, triangles, materials):
+        shapes = R.as_records(shapes, R.SHAPE)
+        triangles = R.as_records(triangles, R.TRIANGLE)
+        materials = R.as_records(materials, R.MATERIAL)
+        sd = R.as_records(self.scene_data, R.SCENE_DATA)
+        self._check(self.lib.srt_update_scene(self._h, _ptr(shapes), len(shapes), _ptr(triangles), len(triangles),
+                                              _ptr(materials), len(materials), _ptr(sd)))
+        self.scene_data["num_shapes"] = len(shapes)  # src/tracer.cpp:94
+
+    def clear_canvas(self):
+        self._check(self.lib.srt_clear_canvas(self._h))
+
+    def render(self, ticks_stopped, output=None):
+        """Tracer::render: trace + resolve + blocking read-back into `output`
+        (uint8, owned_rows*width*4, bytes A,R,G,B)."""
+        if output is None:
+            output = np.zeros(self.owned_rows * self.width * 4, np.uint8)
+        assert output.dtype == np.uint8 and output.size >= self.owned_rows * self.width * 4
+        rd = R.as_records(self.options, R.RENDER_DATA)
+        self._check(self.lib.srt_render(self._h, _ptr(rd), ticks_stopped, _ptr(output)))
+        return output
+
+    # -- extras --
+    def trace(self):
+        rd = R.as_records(self.options, R.RENDER_DATA)
+        self._check(self.lib.srt_trace(self._h, _ptr(rd)))
+
+    def resolve(self, ticks_stopped):
+        self._check(self.lib.srt_resolve(self._h, ticks_stopped))
+
+    def synchronize(self):
+        self._check(self.lib.srt_synchronize(self._h))
+
+    def read_canvas(self):
+        out = np.zeros((self.owned_rows, self.width, 4), np.float32)
+        self._check(self.lib.srt_read_canvas(self._h, _ptr(out)))
+        return out
+
+    def read_argb(self):
+        out = np.zeros((self.owned_rows, self.width, 4), np.uint8)
+        self._check(self.lib.srt_read_argb(self._h, _ptr(out)))
+        return out
+
+    def counters(self):
+        c = Counters()
+        self._check(self.lib.srt_get_counters(self._h, C.byref(c)))
+        return c.as_dict()
+
+    def reset_counters(self):
+        self._check(self.lib.srt_reset_counters(self._h))
+
+    def count_triangles(self, enable=True):
+        self._check(self.lib.srt_set_count_triangles(self._h, 1 if enable else 0))
+
+    def last_kernel_ms(self):
+        a, b = C.c_float(), C.c_float()
+        self._check(self.lib.srt_last_kernel_ms(self._h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def device_buffers(self):
+        cp, cb, ap, ab = C.c_void_p(), C.c_size_t(), C.c_void_p(), C.c_size_t()
+        self._check(self.lib.srt_device_buffers(self._h, C.byref(cp), C.byref(cb), C.byref(ap), C.byref(ab)))
+        return cp.value, cb.value, ap.value, ab.value
+
+    def bind_canvas(self, device_ptr, nbytes):
+        self._check(self.lib.srt_bind_canvas(self._h, C.c_void_p(device_ptr), nbytes))
+
+    def bind_stream(self, hip_stream):
+        self._check(self.lib.srt_bind_stream(self._h, C.c_void_p(hip_stream)))
+
+    def set_partition(self, rank, world, rows_per_block=8):
+        self._check(self.lib.srt_set_partition(self._h, rank, world, rows_per_block))
+        self.owned_rows = self.lib.srt_partition_owned_rows(self.height, rank, world, rows_per_block)
+
+
+# ---- pure-host partition helpers (no GPU) ------------------------------------------
+def owned_rows(height, rank, world, rows_per_block):
+    return load_library().srt_partition_owned_rows(height, rank, world, rows_per_block)
+
+
+def padded_rows(height, world, rows_per_block):
+    return load_library().srt_partition_padded_rows(height, world, rows_per_block)
+
+
+def global_row(height, rank, world, rows_per_block, local_row):
+    return load_library().srt_partition_global_row(height, rank, world, rows_per_block, local_row)
+
+
+def unpermute(gathered, height, world, rows_per_block):
+    """gathered: (world*padded_rows, ...) array, rank-major -> (height, ...) image."""
+    g = np.ascontiguousarray(gathered)
+    row_bytes = g.strides[0]
+    out = np.zeros((height,) + g.shape[1:], g.dtype)
+    rc = load_library().srt_partition_unpermute(_ptr(g), _ptr(out), height, world, rows_per_block, row_bytes)
+    if rc:
+        raise SrtError("srt_partition_unpermute failed")
+    return out

@@ -1,0 +1,39 @@
+"""CPU, only where /root/reference (or a prebuilt oracle/_ref) exists: the restatement
+must be bit-identical to the reference's own render.cl compiled for x86-64."""
+import numpy as np
+
+from conftest import bits_equal
+from simple_raytracer_amd import records as R, scenes as S
+
+
+def _both(oracle, ref, scene, sky, w, h, spp, **kw):
+    shapes, tris, mats = scene
+    rd = R.render_data(w, h, spp, 10, camera_to_world=S.default_camera(), **kw)
+    sd = R.scene_data(len(shapes))
+    a = oracle.render(rd, sd, shapes, tris, mats, sky, nthreads=4)
+    b = ref.render(rd, sd, shapes, tris, mats, sky, nthreads=4)
+    return a, b
+
+
+def test_sphere_scene_config0_slice(oracle, ref, sky):
+    a, b = _both(oracle, ref, S.sphere_scene(), sky, 256, 32, 16)  # a 32-row slab of config[0]
+    assert bits_equal(a, b)
+
+
+def test_mesh_scene(oracle, ref, sky):
+    a, b = _both(oracle, ref, S.mesh_scene(2), sky, 80, 45, 2)
+    assert bits_equal(a, b)
+
+
+def test_random_time_seeds(oracle, ref, sky):
+    for tm in (1, 2**31, 0xFFFFFFFF, 1700000000123 & 0xFFFFFFFF):
+        a, b = _both(oracle, ref, S.mixed_test_scene(), sky, 40, 30, 2, time=tm)
+        assert bits_equal(a, b)
+
+
+def test_average_bytes(oracle, ref, sky):
+    a, _ = _both(oracle, ref, S.sphere_scene(), sky, 64, 48, 4)
+    a[0, 0, :3] = np.nan  # NaN poisoning must resolve to byte 0, not crash
+    a[0, 1, :3] = (1e9, 0.0, -1.0)
+    for steps in (1, 3):
+        assert np.array_equal(oracle.average(steps, a), ref.average(steps, a))

@@ -1,0 +1,260 @@
+#!/usr/bin/env python3
+"""bench.py — headline metric of BASELINE.json: Mray/s of the path-tracing hot path.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload NAME]
+  (N > 1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
+
+Step   = one dispatch of the hot path over the whole frame of the workload: clear the
+         accumulation canvas, trace (the `render` kernel), [N > 1: ONE gather of the
+         packed per-rank canvases to rank 0 over RCCL + unpermute], resolve (the
+         `average` kernel) on rank 0. Inputs and outputs stay in HBM.
+Default workload = BASELINE.json configs[1]: the 7-shape sphere scene, 1920x1080,
+         1024 spp in one dispatch, 10 bounces, one MI355X. With N GPUs the SAME frame
+         is split in interleaved 8-row blocks ("strong" scaling).
+value  = rays (closest-hit queries, counted exactly by the kernel) of all ranks per
+         second of max-over-ranks wall time, in Mray/s.
+roofline: the trace kernel is VALU-issue bound, not HBM bound:
+         achieved = algorithmic lane-ops (W_ops formula of SURVEY.md §8d from the
+         kernel's deterministic counters) / HIP-event kernel time; the HBM side
+         (W_bytes / time against 8 TB/s) is reported next to it.
+cpu_baseline: the CPU oracle (a port; the reference's boost.compute CPU device cannot
+         exist here) on a strided row sample of the same frame, rank 0, N = 1 only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+import srt_pkg  # noqa: E402
+
+srt_pkg.load()
+from simple_raytracer_amd import build as B, multi, records as R, scenes as S, tracer as T  # noqa: E402
+
+VALU_PEAK_LANE_OPS = 256 * 4 * 32 * 2.4e9  # 78.6e12 lane-ops/s: 256 CU x 4 SIMD-32 x 2.4 GHz (MI355X_MICROARCH.md)
+HBM_PEAK = 8.0e12                            # B/s spec (MI355X_MICROARCH.md §HBM)
+
+WORKLOADS = {
+    # name: (scene builder, width, height, spp, bounces, description)
+    "spheres_1080p_1024spp": (S.sphere_scene, 1920, 1080, 1024, 10, "BASELINE configs[1]: 7-shape sphere scene 1920x1080 1024spp"),
+    "spheres_256_16spp": (S.sphere_scene, 256, 256, 16, 10, "BASELINE configs[0]: 7-shape sphere scene 256x256 16spp"),
+    "meshes_1080p_512spp": (lambda: S.mesh_scene(2), 1920, 1080, 512, 10, "BASELINE configs[2]: plane + 2 x 968-triangle meshes 1920x1080 512spp"),
+    "spheres_4k_4096spp": (S.sphere_scene, 3840, 2160, 4096, 10, "BASELINE configs[3]: sphere scene 3840x2160 4096spp"),
+    "mesh100k_1080p_256spp": (lambda: S.mesh_scene(1, 224, 224, smooth=False), 1920, 1080, 256, 10, "BASELINE configs[4]: plane + 99,904-triangle mesh 1920x1080 256spp"),
+}
+
+
+def w_ops(c, shapes):
+    """Algorithmic lane-ops of SURVEY.md §8(d) from deterministic counters."""
+    n_sph = int((shapes["type"] == R.SHAPE_SPHERE).sum())
+    n_pl = int((shapes["type"] == R.SHAPE_PLANE).sum())
+    n_mod = int((shapes["type"] == R.SHAPE_MODEL).sum())
+    rays, paths, sky = c["rays"], c["paths"], c["sky"]
+    bounces = rays - paths  # every path has exactly one non-bouncing final segment
+    return (rays * n_sph * 17 + rays * n_pl * 14 + rays * n_mod * 24 + rays * 3 + c["tri_tests"] * 30
+            + c["tri_pass_u"] * 22 + bounces * 250 + sky * 40 + paths * 30)
+
+
+def w_bytes(c, pixels, scene_bytes, sky_bytes):
+    """Compulsory HBM bytes of one trace launch: canvas RMW 32 B/pixel
+    (+ resolve 20 B/pixel counted with the resolve kernel) + scene + touched sky texels."""
+    return 32 * pixels + scene_bytes + min(sky_bytes, 64 * c["sky"])
+
+
+def cpu_baseline(name, sky, target_seconds=15.0):
+    """Oracle on the host cores over rows y0, y0+stride, ... of the SAME frame."""
+    from oracle import oracle_py  # cpu_baseline leg only
+    oracle_py.build()
+    orc = oracle_py.Oracle("oracle")
+    builder, w, h, spp, nb, _ = WORKLOADS[name]
+    shapes, tris, mats = builder()
+    rd = R.render_data(w, h, spp, nb, camera_to_world=S.default_camera(), time=12345)
+    sd = R.scene_data(len(shapes))
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    threads = max(1, min(cores, 64))
+    # calibrate on a thin sample, then size the real one for ~target_seconds
+    probe_rd = rd.copy()
+    probe_rd["num_samples"] = max(1, min(spp, 16))
+    t0 = time.time()
+    _, c0 = orc.render(probe_rd, sd, shapes, tris, mats, sky, rows=(4, h), row_stride=max(1, h // 16), nthreads=threads, counters=True)
+    dt0 = max(time.time() - t0, 1e-4)
+    paths_per_s = c0["paths"] / dt0
+    rows_wanted = int(max(1, min(h, target_seconds * paths_per_s / (w * spp))))
+    stride = max(1, h // rows_wanted)
+    y0 = stride // 2
+    t0 = time.time()
+    _, c = orc.render(rd, sd, shapes, tris, mats, sky, rows=(y0, h), row_stride=stride, nthreads=threads, counters=True)
+    dt = time.time() - t0
+    n_rows = len(range(y0, h, stride))
+    return {
+        "value": round(c["rays"] / dt / 1e6, 3), "unit": "Mray/s", "cores": threads, "kind": "port",
+        "sample": f"oracle/srt_oracle.c (bit-identical port of render.cl), rows {y0}::{stride} ({n_rows} of {h} rows x {w} px x {spp} spp = {c['paths']} paths, {c['rays']} rays) in {dt:.1f} s",
+        "mpath_per_s": round(c["paths"] / dt / 1e6, 3),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="spheres_1080p_1024spp", choices=sorted(WORKLOADS))
+    ap.add_argument("--spp", type=int, default=0, help="override samples per pixel (development only; makes the line non-comparable)")
+    ap.add_argument("--rows-per-block", type=int, default=8)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
+        args.gpus = world
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    B.build_hip()
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    builder, w, h, spp, nb, desc = WORKLOADS[args.workload]
+    if args.spp:
+        spp = args.spp
+    shapes, tris, mats = builder()
+    sky = S.synthetic_sky()
+
+    t = T.Tracer(w, h, device=local_rank)
+    # One non-default torch stream carries BOTH the library's launches and the RCCL
+    # gather, so trace -> gather -> resolve are ordered without host syncs. (torch's
+    # default stream is the NULL stream, which a non-blocking stream does not order with.)
+    stream = torch.cuda.Stream(device=dev)
+    torch.cuda.set_stream(stream)
+    t.bind_stream(stream.cuda_stream)
+    t.set_skybox(sky)
+    t.options = R.render_data(w, h, spp, nb, camera_to_world=S.default_camera(), time=12345)
+    t.scene_data = R.scene_data(len(shapes))
+    t.update_scene(shapes, tris, mats)
+    part = multi.RowPartition(h, rank, world, args.rows_per_block)
+    canvas_t = torch.zeros((part.padded, w, 4), dtype=torch.float32, device=dev)
+    t.set_partition(rank, world, args.rows_per_block)
+    t.bind_canvas(canvas_t.data_ptr(), canvas_t.numel() * 4)
+    argb_t = torch.zeros((h, w, 4), dtype=torch.uint8, device=dev) if rank == 0 else None
+    unperm = torch.as_tensor(multi.unpermute_index(h, world, args.rows_per_block, part.padded), device=dev) if (rank == 0 and world > 1) else None
+    gather_bufs = [torch.empty_like(canvas_t) for _ in range(world)] if (rank == 0 and world > 1) else None
+
+    trace_ms, resolve_ms = [], []
+
+    def step(record):
+        t.clear_canvas()
+        t.trace()
+        if world > 1:
+            dist.gather(canvas_t, gather_bufs, dst=0)  # the ONE collective of the path (RCCL over xGMI)
+            if rank == 0:
+                full = torch.cat(gather_bufs, dim=0).index_select(0, unperm)
+                t.resolve_external(full.data_ptr(), w * h, 1, argb_t.data_ptr())
+        elif rank == 0:
+            t.resolve_external(canvas_t.data_ptr(), w * h, 1, argb_t.data_ptr())
+        if record:
+            a, b = t.last_kernel_ms()  # HIP events on the launch stream (synchronises it)
+            trace_ms.append(a)
+            resolve_ms.append(b)
+
+    def fence():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        step(False)
+    fence()
+    t.reset_counters()
+    t.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step(True)
+    fence()
+    elapsed = time.perf_counter() - t0
+
+    c = t.counters()
+    stats = torch.tensor([elapsed, float(np.mean(trace_ms)) if trace_ms else 0.0], dtype=torch.float64, device=dev)
+    cnt = torch.tensor([c["rays"], c["paths"], c["sky"], c["nan_pixels"]], dtype=torch.int64, device=dev)
+    if world > 1:
+        dist.all_reduce(stats, op=dist.ReduceOp.MAX)
+        dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
+    elapsed_max, trace_ms_max = float(stats[0]), float(stats[1])
+    rays, paths, nsky, nan_px = (int(v) for v in cnt.tolist())
+
+    if rank == 0:
+        steps = max(args.steps, 1)
+        per = {"rays": rays // steps, "paths": paths // steps, "sky": nsky // steps, "tri_tests": 0, "tri_pass_u": 0}
+        if (shapes["type"] == R.SHAPE_MODEL).any() and world == 1:
+            # triangle counters come from the instrumented kernel variant, outside the timed region
+            t.count_triangles(True)
+            t.reset_counters()
+            t.clear_canvas()
+            t.trace()
+            ci = t.counters()
+            per["tri_tests"], per["tri_pass_u"] = ci["tri_tests"], ci["tri_pass_u"]
+            t.count_triangles(False)
+        ops = w_ops(per, shapes)
+        scene_bytes = shapes.nbytes + tris.nbytes + mats.nbytes
+        nbytes = w_bytes(per, w * h, scene_bytes, sky.nbytes)
+        kt = trace_ms_max * 1e-3 if trace_ms_max > 0 else elapsed_max / steps
+        achieved = ops / kt / 1e12 / world  # per-GPU rate: each GPU ran 1/world of the ops in kt
+        traffic = None
+        tf = ROOT / "profiles" / "traffic.json"
+        if tf.exists():
+            try:
+                traffic = json.loads(tf.read_text()).get(args.workload if not args.spp else "", {}).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        line = {
+            "metric": "Mray/s at 1920x1080x1024spp" if args.workload == "spheres_1080p_1024spp" and not args.spp else f"Mray/s ({args.workload})",
+            "value": round(rays / elapsed_max / 1e6, 2),
+            "unit": "Mray/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(elapsed_max / steps * 1e3, 3),
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": desc + (f" [spp overridden to {spp}]" if args.spp else ""), "width": w, "height": h, "spp": spp,
+                       "bounces": nb, "shapes": int(len(shapes)), "triangles": int(len(tris)), "partition": f"{world} x interleaved {args.rows_per_block}-row blocks" if world > 1 else "single GPU",
+                       "mode": "parity (fp-contract off, IEEE div/sqrt; canvas bit-identical to the CPU oracle)"},
+            "mpath_per_s": round(paths / elapsed_max / 1e6, 2),
+            "rays_per_step": per["rays"], "paths_per_step": per["paths"], "nan_pixels": nan_px,
+            "kernel_ms": {"trace": round(trace_ms_max, 3), "resolve": round(float(np.mean(resolve_ms)) if resolve_ms else 0.0, 4)},
+            "roofline": {
+                "bound": "valu", "achieved": round(achieved, 3), "peak": round(VALU_PEAK_LANE_OPS / 1e12, 1), "unit": "Tlane-op/s",
+                "frac": round(achieved * 1e12 / VALU_PEAK_LANE_OPS, 4), "traffic": traffic,
+                "kernel": "srt_trace_kernel", "algorithmic_ops_per_launch": int(ops // world),
+                "note": "VALU-issue roofline (SURVEY.md §8d/H8): 256 CU x 4 SIMD x 32 lanes x 2.4 GHz; ops = W_ops formula over exact kernel counters",
+                "hbm": {"achieved": round(nbytes / world / kt / 1e9, 2), "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                        "frac": round(nbytes / world / kt / HBM_PEAK, 6), "algorithmic_bytes_per_launch": int(nbytes // world)},
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(args.workload, sky)
+        print(json.dumps(line), flush=True)
+    t.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -88,6 +88,10 @@ int srt_render(srt_tracer *t, const srt_render_data *options, uint32_t ticks_sto
 int srt_trace(srt_tracer *t, const srt_render_data *options);      /* `render` kernel, render.cl:483 */
 int srt_resolve(srt_tracer *t, uint32_t ticks_stopped);             /* `average` kernel, render.cl:525 */
 int srt_synchronize(srt_tracer *t);
+/* The `average` kernel over caller-owned device buffers (num_pixels float4 in,
+ * num_pixels*4 bytes out), e.g. the gathered full canvas on the root GPU. Async. */
+int srt_resolve_external(srt_tracer *t, const void *device_canvas, uint32_t num_pixels, uint32_t ticks_stopped,
+                         void *device_argb);
 
 /* ---- results / introspection ---------------------------------------------------- */
 

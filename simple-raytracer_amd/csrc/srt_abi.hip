@@ -381,6 +381,24 @@ int srt_resolve(srt_tracer *t, uint32_t ticks_stopped) {
 	return SRT_OK;
 }
 
+int srt_resolve_external(srt_tracer *t, const void *device_canvas, uint32_t num_pixels, uint32_t ticks_stopped,
+                         void *device_argb) {
+	if (!t) return SRT_ERR_INVALID;
+	if (!device_canvas || !device_argb) return fail(t, SRT_ERR_INVALID, "srt_resolve_external: NULL buffer");
+	SRT_HIP(t, hipSetDevice(t->device));
+	ResolveParams rp;
+	rp.canvas = static_cast<const float *>(device_canvas);
+	rp.argb = static_cast<uint8_t *>(device_argb);
+	rp.num_steps = ticks_stopped;
+	rp.num_pixels = num_pixels;
+	SRT_HIP(t, hipEventRecord(t->ev_r0, t->stream));
+	srt_launch_resolve(rp, t->stream);
+	SRT_HIP(t, hipGetLastError());
+	SRT_HIP(t, hipEventRecord(t->ev_r1, t->stream));
+	t->have_resolve_ev = true;
+	return SRT_OK;
+}
+
 int srt_synchronize(srt_tracer *t) {
 	if (!t) return SRT_ERR_INVALID;
 	SRT_HIP(t, hipSetDevice(t->device));

@@ -1,0 +1,121 @@
+// tracer.hpp — `class Tracer` with the reference's public interface
+// (/root/reference/include/tracer.hpp:26-88), implemented over the C ABI of
+// libsrt_hip.so instead of boost.compute/OpenCL. The front-end's call sequence
+// (src/main.cpp:114-126, 277-290) works unchanged:
+//
+//     Tracer tracer(w, h);  tracer.options.num_samples = 2; tracer.scene_data.sun_focus = ...
+//     tracer.clear_canvas(); tracer.update_scene(shapes, triangles, materials.materials);
+//     tracer.options.camera_to_world = camera_mat; ...; tracer.render(ticks, pixels);
+//
+// Differences a maintainer must know: no run-time files are read
+// (render.cl is gone; the skybox is handed over decoded via set_skybox), and failures
+// throw std::runtime_error carrying srt_last_error() where boost.compute threw.
+#pragma once
+
+#include <cstdint>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/srt_abi.h"
+#include "color.hpp"
+#include "material.hpp"
+#include "shape.hpp"
+
+#define VEC3TOCL(v) (cl_float3({{(v).x, (v).y, (v).z}}))
+#define VEC4TOCL(v) (cl_float4({{(v).x, (v).y, (v).z, (v).w}}))
+
+class Tracer {
+  private:
+	srt_tracer *handle = nullptr;
+
+	void check(int rc) const {
+		if (rc != SRT_OK) throw std::runtime_error(std::string("srt: ") + srt_last_error(handle));
+	}
+
+  public:
+	struct RenderData {
+		cl_int width, height;
+		cl_int num_samples;
+		cl_int num_bounces;
+		cl_float aspect_ratio;
+		cl_float fov_scale;
+		bool show_normals;
+
+		alignas(cl_float4) glm::mat4 camera_to_world;
+
+		cl_uint time;
+		cl_uint tick;
+
+		RenderData(int width, int height)
+			: width(width), height(height), num_samples(4), num_bounces(10), aspect_ratio(float(width) / float(height)),
+			  fov_scale(1.0f), show_normals(false), camera_to_world(1.0f), time(1), tick(0) {}
+	} options;
+
+	struct SceneData {
+		cl_int num_shapes;
+		cl_float sun_focus;
+		cl_float sun_intensity;
+
+		alignas(cl_float3) Color horizon_color;
+		alignas(cl_float3) Color zenith_color;
+		alignas(cl_float3) Color ground_color;
+		alignas(cl_float3) Color sun_color;
+
+		cl_float3 sun_direction;
+	} scene_data;
+
+	Tracer(const int width, const int height, const int device = 0) : options(width, height), scene_data() {
+		int rc = srt_create(width, height, device, &handle);
+		if (rc != SRT_OK) throw std::runtime_error(std::string("srt_create: ") + srt_last_error(nullptr));
+	}
+	~Tracer() { srt_destroy(handle); }
+	Tracer(const Tracer &) = delete;
+	Tracer &operator=(const Tracer &) = delete;
+
+	/// replaces the stbi_loadf + enqueue_write_image of the reference's constructor:
+	/// `rgba` = width*height RGBA32F texels, row 0 = bottom of the picture
+	void set_skybox(const float *rgba, int width, int height) { check(srt_set_skybox(handle, rgba, width, height)); }
+
+	void update_scene(
+		const std::vector<Shape> &shapes, const std::vector<Triangle> &triangles, const std::vector<Material> &materials
+	) {
+		static_assert(sizeof(SceneData) == sizeof(srt_scene_data), "SceneData layout");
+		check(srt_update_scene(
+			handle, reinterpret_cast<const srt_shape *>(shapes.data()), shapes.size(),
+			reinterpret_cast<const srt_triangle *>(triangles.data()), triangles.size(),
+			reinterpret_cast<const srt_material *>(materials.data()), materials.size(),
+			reinterpret_cast<const srt_scene_data *>(&scene_data)
+		));
+		scene_data.num_shapes = (cl_int)shapes.size();
+	}
+
+	void clear_canvas() { check(srt_clear_canvas(handle)); }
+
+	/// trace + resolve + blocking read-back of width*height*4 bytes (A,R,G,B)
+	void render(cl_uint ticks_stopped, std::vector<uint8_t> &output) {
+		static_assert(sizeof(RenderData) == sizeof(srt_render_data), "RenderData layout");
+		if (output.size() < size_t(options.width) * size_t(options.height) * 4)
+			throw std::runtime_error("Tracer::render: output must hold width*height*4 bytes");
+		check(srt_render(handle, reinterpret_cast<const srt_render_data *>(&options), ticks_stopped, output.data()));
+	}
+
+	// -- extras beyond the reference's interface --
+	void read_canvas(std::vector<float> &rgba) {
+		rgba.resize(size_t(options.width) * size_t(options.height) * 4);
+		check(srt_read_canvas(handle, rgba.data()));
+	}
+	srt_counters counters() {
+		srt_counters c;
+		check(srt_get_counters(handle, &c));
+		return c;
+	}
+	srt_tracer *native_handle() { return handle; }
+};
+
+static_assert(offsetof(Tracer::RenderData, camera_to_world) == offsetof(srt_render_data, camera_to_world), "RenderData.camera_to_world");
+static_assert(offsetof(Tracer::RenderData, time) == offsetof(srt_render_data, time), "RenderData.time");
+static_assert(offsetof(Tracer::RenderData, show_normals) == offsetof(srt_render_data, show_normals), "RenderData.show_normals");
+static_assert(offsetof(Tracer::SceneData, sun_color) == offsetof(srt_scene_data, sun_color), "SceneData.sun_color");
+static_assert(offsetof(Tracer::SceneData, sun_direction) == offsetof(srt_scene_data, sun_direction), "SceneData.sun_direction");
+static_assert(offsetof(Tracer::SceneData, horizon_color) == offsetof(srt_scene_data, horizon_color), "SceneData.horizon_color");

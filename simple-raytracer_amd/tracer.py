@@ -19,7 +19,7 @@ LIB_PATH = PKG / "lib" / "libsrt_hip.so"
 # every symbol include/srt_abi.h declares
 ABI_SYMBOLS = [
     "srt_create", "srt_destroy", "srt_last_error", "srt_set_skybox", "srt_update_scene", "srt_clear_canvas",
-    "srt_render", "srt_trace", "srt_resolve", "srt_synchronize", "srt_read_canvas", "srt_read_argb",
+    "srt_render", "srt_trace", "srt_resolve", "srt_resolve_external", "srt_synchronize", "srt_read_canvas", "srt_read_argb",
     "srt_get_counters", "srt_set_count_triangles", "srt_reset_counters", "srt_last_kernel_ms",
     "srt_device_buffers", "srt_bind_canvas", "srt_bind_stream", "srt_set_partition",
     "srt_partition_owned_rows", "srt_partition_padded_rows", "srt_partition_global_row",
@@ -62,6 +62,7 @@ def load_library():
     lib.srt_trace.argtypes = [vp, vp]
     lib.srt_resolve.argtypes = [vp, C.c_uint32]
     lib.srt_synchronize.argtypes = [vp]
+    lib.srt_resolve_external.argtypes = [vp, vp, C.c_uint32, C.c_uint32, vp]
     lib.srt_read_canvas.argtypes = [vp, vp]
     lib.srt_read_argb.argtypes = [vp, vp]
     lib.srt_get_counters.argtypes = [vp, C.POINTER(Counters)]
@@ -152,6 +153,9 @@ class Tracer:
 
     def resolve(self, ticks_stopped):
         self._check(self.lib.srt_resolve(self._h, ticks_stopped))
+
+    def resolve_external(self, canvas_ptr, num_pixels, ticks_stopped, argb_ptr):
+        self._check(self.lib.srt_resolve_external(self._h, C.c_void_p(canvas_ptr), num_pixels, ticks_stopped, C.c_void_p(argb_ptr)))
 
     def synchronize(self):
         self._check(self.lib.srt_synchronize(self._h))

@@ -48,6 +48,24 @@ def build_hip(force=False, verbose=False, extra_flags=()):
     return LIB
 
 
+HEADLESS = LIBDIR / "srt_headless"
+
+
+def build_headless(force=False):
+    """g++ build of tools/srt_headless.cpp (the C++ host mirror's driver) against the .so."""
+    src = PKG / "tools" / "srt_headless.cpp"
+    deps = [src] + sorted((PKG / "host").glob("*.hpp"))
+    build_hip()
+    if not force and HEADLESS.exists() and all(d.stat().st_mtime <= HEADLESS.stat().st_mtime for d in deps + [LIB]):
+        return HEADLESS
+    cmd = ["g++", "-std=c++17", "-O2", "-Wall", "-ffp-contract=off", str(src), "-o", str(HEADLESS), f"-L{LIBDIR}", "-lsrt_hip",
+           "-Wl,-rpath,$ORIGIN"]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("g++ failed:\n" + r.stdout + r.stderr)
+    return HEADLESS
+
+
 if __name__ == "__main__":
     import sys
     print(build_hip(force="--force" in sys.argv, verbose=True))

@@ -23,6 +23,33 @@ struct LoopShape {
 };
 static_assert(sizeof(LoopShape) == 48, "LoopShape 48 B");
 
+/* v2 layout of the same information. Consecutive shapes of one type form a RUN; the
+ * kernel walks runs in array order (so the first-of-equal-t rule of render.cl:306 is
+ * kept) and, inside a run, reads homogeneous packed records with wide scalar loads:
+ *   sphere: 4 dwords  {cx, cy, cz, r*r}                    -> 4 spheres per s_load_dwordx16
+ *   plane : 8 dwords  {px, py, pz, 0, nx, ny, nz, 0}       -> 2 planes per s_load_dwordx16
+ *   model : 8 dwords  {min.x, min.y, min.z, first_wtri(bits), max.x, max.y, max.z, count(bits)}
+ * data_off is in dwords into the packed array and is a multiple of 16 (64 B). */
+struct ShapeRun {
+	int32_t type;
+	uint32_t first_shape;
+	uint32_t count;
+	uint32_t data_off;
+};
+static_assert(sizeof(ShapeRun) == 16, "ShapeRun 16 B");
+
+/* Per-shape record for the per-lane winner lookup after the loop (staged in LDS):
+ *   sphere: v = centre, w = radius; plane: v = normal; model: unused (rare path reads
+ *   the srt_shape itself). */
+struct WinnerRec {
+	int32_t type;
+	int32_t material;
+	float vx, vy, vz, w;
+	uint32_t first_wtri;
+	uint32_t _pad;
+};
+static_assert(sizeof(WinnerRec) == 32, "WinnerRec 32 B");
+
 /* World-space triangle written by the pre-pass: v0, e1 = v1 - v0, e2 = v2 - v0 with
  * v = transform * pos in the operation order of render.cl:114-120, so each value is
  * bit-identical to what the reference recomputes per ray (render.cl:325-328,247-248). */
@@ -34,6 +61,13 @@ struct TraceParams {
 	srt_render_data rd;
 	srt_scene_data sd;
 	const LoopShape *loop_shapes;
+	const ShapeRun *runs;
+	const float *run_data;
+	const WinnerRec *winners;
+	int32_t num_runs;
+	int32_t num_materials;
+	uint32_t lds_bytes; /* dynamic LDS given to the launch; 0 = winners/materials stay in global memory */
+	int32_t _pad0;
 	const srt_shape *shapes;
 	const srt_triangle *triangles;
 	const srt_material *materials;
@@ -62,7 +96,7 @@ struct ResolveParams {
 	uint32_t num_pixels;
 };
 
-void srt_launch_trace(const TraceParams &p, bool count_triangles, void *stream);
+void srt_launch_trace(TraceParams p, bool count_triangles, void *stream);
 void srt_launch_prepass(const PrepassParams &p, uint64_t total_wtris, void *stream);
 void srt_launch_resolve(const ResolveParams &p, void *stream);
 

@@ -86,6 +86,87 @@ __device__ __forceinline__ float schlick(float mu, float cos_theta) {
 	return (float)((double)r0 + (1.0 - (double)r0) * x5);
 }
 
+
+// ---- wave-uniform scene data: 64-byte blocks fetched with ONE scalar load each ----
+struct alignas(64) Blk16 {
+	float v[16];
+};
+
+__device__ __forceinline__ uint32_t f2u(float f) { return __float_as_uint(f); }
+
+// render.cl:180-204 against one sphere held in SGPRs; updates the lane's closest hit
+__device__ __forceinline__ void test_sphere(float cx, float cy, float cz, float r2, f3 org, f3 dir, int idx, float &tmin, int &best) {
+	f3 L = mk(cx - org.x, cy - org.y, cz - org.z);
+	float b = dot3(L, dir);
+	float c = dot3(L, L) - r2;
+	float disc = b * b - c;
+	float sq = dm_sqrtf(disc);
+	float t = b - sq;
+	if (t < 0.0f) t = b + sq;
+	bool hit = !(disc < 0.0f) && !(t < 0.0f);
+	if (hit && t < tmin) {
+		tmin = t;
+		best = idx;
+	}
+}
+
+// render.cl:206-221
+__device__ __forceinline__ void test_plane(float px, float py, float pz, float nx, float ny, float nz, f3 org, f3 dir, int idx, float &tmin,
+                                           int &best) {
+	f3 n = mk(nx, ny, nz);
+	float denom = dot3(n, dir);
+	float t = dot3(n, mk(px - org.x, py - org.y, pz - org.z)) / denom;
+	bool hit = !(dm_fabs(denom) == 0.0f) && !(t < 0.0f);
+	if (hit && t < tmin) {
+		tmin = t;
+		best = idx;
+	}
+}
+
+// render.cl:279-290 with tmax = the lane's current closest t
+__device__ __forceinline__ bool test_aabb(float lx, float ly, float lz, float hx, float hy, float hz, f3 org, f3 inv, float tmax) {
+	float t0 = 0.0f, t1 = tmax;
+	float a1 = (lx - org.x) * inv.x, a2 = (hx - org.x) * inv.x;
+	t0 = dm_max(t0, dm_min(a1, a2));
+	t1 = dm_min(t1, dm_max(a1, a2));
+	a1 = (ly - org.y) * inv.y, a2 = (hy - org.y) * inv.y;
+	t0 = dm_max(t0, dm_min(a1, a2));
+	t1 = dm_min(t1, dm_max(a1, a2));
+	a1 = (lz - org.z) * inv.z, a2 = (hz - org.z) * inv.z;
+	t0 = dm_max(t0, dm_min(a1, a2));
+	t1 = dm_min(t1, dm_max(a1, a2));
+	return t0 < t1;
+}
+
+// Moller-Trumbore (render.cl:243-275) over the pre-pass triangles [first, first+count)
+template <bool COUNT_TRIS>
+__device__ __forceinline__ void test_triangles(const float *__restrict__ wtris, uint32_t first, uint32_t count, f3 org, f3 dir, int idx,
+                                               float &tmin, int &best, uint32_t &best_tri, uint32_t &n_tri_u) {
+	for (uint32_t j = 0; j < count; j++) {
+		const float *__restrict__ w = wtris + (size_t)(first + j) * SRT_WTRI_FLOATS;
+		f3 v0 = mk(w[0], w[1], w[2]);
+		f3 e1 = mk(w[3], w[4], w[5]);
+		f3 e2 = mk(w[6], w[7], w[8]);
+		f3 h = cross3(dir, e2);
+		float a = dot3(e1, h);
+		float f = 1.0f / a;
+		f3 sv = org - v0;
+		float u = f * dot3(sv, h);
+		bool ok = !(a == 0.0f) && !(u < 0.0f || u > 1.0f);
+		if (COUNT_TRIS) n_tri_u += ok ? 1u : 0u;
+		f3 q = cross3(sv, e1);
+		float v = f * dot3(dir, q);
+		ok = ok && !(v < 0.0f || u + v > 1.0f);
+		float t = f * dot3(e2, q);
+		ok = ok && t > 0.0f;
+		if (ok && t < tmin) {
+			tmin = t;
+			best = idx;
+			best_tri = j;
+		}
+	}
+}
+
 // global y of packed local row (include/srt_abi.h srt_set_partition)
 __device__ __forceinline__ int global_row(int local_row, int rank, int world, int rpb) {
 	int lb = local_row / rpb;
@@ -131,8 +212,9 @@ __device__ __forceinline__ f3 sky_box(const TraceParams &p, f3 dir) {
 // ---------------------------------------------------------------------------------
 // Trace kernel. 64-thread workgroups = one wave = one 8x8 pixel tile.
 // ---------------------------------------------------------------------------------
-template <bool COUNT_TRIS>
+template <bool COUNT_TRIS, bool USE_LDS>
 __global__ __launch_bounds__(64) void srt_trace_kernel(const TraceParams p) {
+	extern __shared__ float4 lds[]; // [2*n_shapes] winner records, then [4*n_materials] materials
 	const int width = p.rd.width;
 	const int tiles_x = (width + 7) >> 3;
 	const int tile = blockIdx.x;
@@ -146,8 +228,17 @@ __global__ __launch_bounds__(64) void srt_trace_kernel(const TraceParams p) {
 	const int ns = p.rd.num_samples;
 	const int nb = p.rd.num_bounces;
 	const int n_shapes = p.sd.num_shapes;
-	const LoopShape *__restrict__ loop_shapes = p.loop_shapes;
+	const ShapeRun *__restrict__ runs = p.runs;
+	const float *__restrict__ run_data = p.run_data;
 	const float *__restrict__ wtris = p.wtris;
+
+	if (USE_LDS) {
+		const float4 *__restrict__ gw = reinterpret_cast<const float4 *>(p.winners);
+		const float4 *__restrict__ gm = reinterpret_cast<const float4 *>(p.materials);
+		for (int i = threadIdx.x; i < 2 * n_shapes; i += 64) lds[i] = gw[i];
+		for (int i = threadIdx.x; i < 4 * p.num_materials; i += 64) lds[2 * n_shapes + i] = gm[i];
+		__syncthreads();
+	}
 
 	f3 sum = mk(0.f, 0.f, 0.f);
 	f3 org = mk(0.f, 0.f, 0.f), dir = mk(0.f, 0.f, 0.f), mask = mk(1.f, 1.f, 1.f), color = mk(0.f, 0.f, 0.f);
@@ -183,73 +274,36 @@ __global__ __launch_bounds__(64) void srt_trace_kernel(const TraceParams p) {
 			f3 inv = mk(0.f, 0.f, 0.f);
 			if (p.num_models > 0) inv = mk(1.0f / dir.x, 1.0f / dir.y, 1.0f / dir.z);
 
-			for (int i = 0; i < n_shapes; i++) {
-				const LoopShape &s = loop_shapes[i];
-				if (s.type == SRT_SHAPE_SPHERE) {
-					// render.cl:180-204
-					f3 L = mk(s.f[0] - org.x, s.f[1] - org.y, s.f[2] - org.z);
-					float b = dot3(L, dir);
-					float c = dot3(L, L) - s.f[3];
-					float disc = b * b - c;
-					float sq = dm_sqrtf(disc);
-					float t = b - sq;
-					if (t < 0.0f) t = b + sq;
-					bool hit = !(disc < 0.0f) && !(t < 0.0f);
-					if (hit && t < tmin) {
-						tmin = t;
-						best = i;
+			for (int r = 0; r < p.num_runs; r++) {
+				const ShapeRun run = runs[r];
+				const float *__restrict__ d = run_data + run.data_off;
+				const int base = (int)run.first_shape;
+				const uint32_t cnt = run.count;
+				if (run.type == SRT_SHAPE_SPHERE) {
+					for (uint32_t k = 0; k < cnt; k += 4) {
+						const Blk16 b = *reinterpret_cast<const Blk16 *>(d + 4 * k);
+						test_sphere(b.v[0], b.v[1], b.v[2], b.v[3], org, dir, base + (int)k, tmin, best);
+						if (k + 1 < cnt) test_sphere(b.v[4], b.v[5], b.v[6], b.v[7], org, dir, base + (int)k + 1, tmin, best);
+						if (k + 2 < cnt) test_sphere(b.v[8], b.v[9], b.v[10], b.v[11], org, dir, base + (int)k + 2, tmin, best);
+						if (k + 3 < cnt) test_sphere(b.v[12], b.v[13], b.v[14], b.v[15], org, dir, base + (int)k + 3, tmin, best);
 					}
-				} else if (s.type == SRT_SHAPE_MODEL) {
-					// render.cl:279-290, tmax = current closest t
-					float t0 = 0.0f, t1 = tmin;
-					{
-						float a1 = (s.f[0] - org.x) * inv.x, a2 = (s.f[3] - org.x) * inv.x;
-						t0 = dm_max(t0, dm_min(a1, a2));
-						t1 = dm_min(t1, dm_max(a1, a2));
-						a1 = (s.f[1] - org.y) * inv.y, a2 = (s.f[4] - org.y) * inv.y;
-						t0 = dm_max(t0, dm_min(a1, a2));
-						t1 = dm_min(t1, dm_max(a1, a2));
-						a1 = (s.f[2] - org.z) * inv.z, a2 = (s.f[5] - org.z) * inv.z;
-						t0 = dm_max(t0, dm_min(a1, a2));
-						t1 = dm_min(t1, dm_max(a1, a2));
+				} else if (run.type == SRT_SHAPE_PLANE) {
+					for (uint32_t k = 0; k < cnt; k += 2) {
+						const Blk16 b = *reinterpret_cast<const Blk16 *>(d + 8 * k);
+						test_plane(b.v[0], b.v[1], b.v[2], b.v[4], b.v[5], b.v[6], org, dir, base + (int)k, tmin, best);
+						if (k + 1 < cnt) test_plane(b.v[8], b.v[9], b.v[10], b.v[12], b.v[13], b.v[14], org, dir, base + (int)k + 1, tmin, best);
 					}
-					if (t0 < t1) {
-						const uint32_t first = s.a, count = s.b;
-						if (COUNT_TRIS) n_tri += count;
-						for (uint32_t j = 0; j < count; j++) {
-							// Moller-Trumbore (render.cl:243-275) on the pre-pass triangle
-							const float *__restrict__ w = wtris + (size_t)(first + j) * SRT_WTRI_FLOATS;
-							f3 v0 = mk(w[0], w[1], w[2]);
-							f3 e1 = mk(w[3], w[4], w[5]);
-							f3 e2 = mk(w[6], w[7], w[8]);
-							f3 h = cross3(dir, e2);
-							float a = dot3(e1, h);
-							float f = 1.0f / a;
-							f3 sv = org - v0;
-							float u = f * dot3(sv, h);
-							bool ok = !(a == 0.0f) && !(u < 0.0f || u > 1.0f);
-							if (COUNT_TRIS) n_tri_u += ok ? 1u : 0u;
-							f3 q = cross3(sv, e1);
-							float v = f * dot3(dir, q);
-							ok = ok && !(v < 0.0f || u + v > 1.0f);
-							float t = f * dot3(e2, q);
-							ok = ok && t > 0.0f;
-							if (ok && t < tmin) {
-								tmin = t;
-								best = i;
-								best_tri = j;
-							}
+				} else if (run.type == SRT_SHAPE_MODEL) {
+					for (uint32_t k = 0; k < cnt; k += 2) {
+						const Blk16 b = *reinterpret_cast<const Blk16 *>(d + 8 * k);
+						if (test_aabb(b.v[0], b.v[1], b.v[2], b.v[4], b.v[5], b.v[6], org, inv, tmin)) {
+							if (COUNT_TRIS) n_tri += f2u(b.v[7]);
+							test_triangles<COUNT_TRIS>(wtris, f2u(b.v[3]), f2u(b.v[7]), org, dir, base + (int)k, tmin, best, best_tri, n_tri_u);
 						}
-					}
-				} else if (s.type == SRT_SHAPE_PLANE) {
-					// render.cl:206-221
-					f3 n = mk(s.f[3], s.f[4], s.f[5]);
-					float denom = dot3(n, dir);
-					float t = dot3(n, mk(s.f[0] - org.x, s.f[1] - org.y, s.f[2] - org.z)) / denom;
-					bool hit = !(dm_fabs(denom) == 0.0f) && !(t < 0.0f);
-					if (hit && t < tmin) {
-						tmin = t;
-						best = i;
+						if (k + 1 < cnt && test_aabb(b.v[8], b.v[9], b.v[10], b.v[12], b.v[13], b.v[14], org, inv, tmin)) {
+							if (COUNT_TRIS) n_tri += f2u(b.v[15]);
+							test_triangles<COUNT_TRIS>(wtris, f2u(b.v[11]), f2u(b.v[15]), org, dir, base + (int)k + 1, tmin, best, best_tri, n_tri_u);
+						}
 					}
 				}
 			}
@@ -259,17 +313,33 @@ __global__ __launch_bounds__(64) void srt_trace_kernel(const TraceParams p) {
 			f3 pos = org, nrm = mk(0.f, 0.f, 0.f);
 			bool front = false;
 			if (best >= 0) {
-				const srt_shape *__restrict__ sh = p.shapes + best;
-				material_index = sh->material;
-				int type = sh->type;
+				int type;
+				f3 wv;
+				float ww;
+				uint32_t first_wtri;
+				if (USE_LDS) {
+					const float4 w0 = lds[2 * best], w1 = lds[2 * best + 1];
+					type = (int)f2u(w0.x);
+					material_index = (int)f2u(w0.y);
+					wv = mk(w0.z, w0.w, w1.x);
+					ww = w1.y;
+					first_wtri = f2u(w1.z);
+				} else {
+					const WinnerRec *__restrict__ wr = p.winners + best;
+					type = wr->type;
+					material_index = wr->material;
+					wv = mk(wr->vx, wr->vy, wr->vz);
+					ww = wr->w;
+					first_wtri = wr->first_wtri;
+				}
 				pos = org + dir * tmin;
 				if (type == SRT_SHAPE_SPHERE) {
-					nrm = (pos - ld3(sh->shape.sphere.position)) / sh->shape.sphere.radius;
+					nrm = (pos - wv) / ww;
 				} else if (type == SRT_SHAPE_PLANE) {
-					nrm = ld3(sh->shape.plane.normal);
+					nrm = wv;
 				} else {
-					const srt_model *__restrict__ m = &sh->shape.model;
-					const float *__restrict__ w = wtris + (size_t)(loop_shapes[best].a + best_tri) * SRT_WTRI_FLOATS;
+					const srt_model *__restrict__ m = &p.shapes[best].shape.model;
+					const float *__restrict__ w = wtris + (size_t)(first_wtri + best_tri) * SRT_WTRI_FLOATS;
 					f3 v0 = mk(w[0], w[1], w[2]);
 					f3 e1 = mk(w[3], w[4], w[5]);
 					f3 e2 = mk(w[6], w[7], w[8]);
@@ -296,11 +366,14 @@ __global__ __launch_bounds__(64) void srt_trace_kernel(const TraceParams p) {
 					color = mk(nrm.x * 0.5f + 0.5f, nrm.y * 0.5f + 0.5f, nrm.z * 0.5f + 0.5f); // render.cl:407-410
 					done = true;
 				} else {
-					const srt_material *__restrict__ mat = p.materials + material_index;
-					const float4 m0 = *reinterpret_cast<const float4 *>(&mat->smoothness);
-					const float2 m1 = *reinterpret_cast<const float2 *>(&mat->transmittance);
-					const float4 mc = *reinterpret_cast<const float4 *>(&mat->color);
-					const float4 me = *reinterpret_cast<const float4 *>(&mat->emission);
+					float4 m0, m1, mc, me;
+					if (USE_LDS) {
+						const float4 *__restrict__ lm = lds + 2 * n_shapes + 4 * material_index;
+						m0 = lm[0], m1 = lm[1], mc = lm[2], me = lm[3];
+					} else {
+						const float4 *__restrict__ gm = reinterpret_cast<const float4 *>(p.materials + material_index);
+						m0 = gm[0], m1 = gm[1], mc = gm[2], me = gm[3];
+					}
 					const float smoothness = m0.x, metallic = m0.y, specular = m0.z, emission_strength = m0.w;
 					const float transmittance = m1.x, ior = m1.y;
 					const f3 mcolor = mk(mc.x, mc.y, mc.z);
@@ -450,15 +523,23 @@ __global__ __launch_bounds__(256) void srt_resolve_kernel(const ResolveParams p)
 // ---------------------------------------------------------------------------------
 // launch wrappers (host)
 // ---------------------------------------------------------------------------------
-void srt_launch_trace(const TraceParams &p, bool count_triangles, void *stream) {
+void srt_launch_trace(TraceParams p, bool count_triangles, void *stream) {
 	const int tiles_x = (p.rd.width + 7) / 8, tiles_y = (p.owned_rows + 7) / 8;
 	const long long tiles = (long long)tiles_x * tiles_y;
 	if (tiles <= 0) return;
 	dim3 grid((unsigned)tiles), block(64);
-	if (count_triangles)
-		hipLaunchKernelGGL(srt_trace_kernel<true>, grid, block, 0, (hipStream_t)stream, p);
-	else
-		hipLaunchKernelGGL(srt_trace_kernel<false>, grid, block, 0, (hipStream_t)stream, p);
+	// winners + materials go to LDS when small enough not to cost occupancy (16 waves/CU x 8 KB < 160 KB)
+	const size_t need = (size_t)p.sd.num_shapes * sizeof(WinnerRec) + (size_t)p.num_materials * sizeof(srt_material);
+	const bool use_lds = need <= 8192;
+	p.lds_bytes = use_lds ? (uint32_t)need : 0u;
+	hipStream_t st = (hipStream_t)stream;
+	if (use_lds) {
+		if (count_triangles) hipLaunchKernelGGL((srt_trace_kernel<true, true>), grid, block, need, st, p);
+		else hipLaunchKernelGGL((srt_trace_kernel<false, true>), grid, block, need, st, p);
+	} else {
+		if (count_triangles) hipLaunchKernelGGL((srt_trace_kernel<true, false>), grid, block, 0, st, p);
+		else hipLaunchKernelGGL((srt_trace_kernel<false, false>), grid, block, 0, st, p);
+	}
 }
 
 void srt_launch_prepass(const PrepassParams &p, uint64_t max_tris_per_model, void *stream) {

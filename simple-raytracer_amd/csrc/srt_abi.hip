@@ -48,7 +48,11 @@ struct srt_tracer {
 	size_t canvas_bytes = 0; // of the buffer in use
 	DevBuf<uint8_t> argb;
 	DevBuf<srt_shape> shapes;
-	DevBuf<LoopShape> loop_shapes;
+	DevBuf<ShapeRun> runs;
+	DevBuf<float> run_data;
+	DevBuf<WinnerRec> winners;
+	int num_runs = 0;
+	size_t num_materials = 0;
 	DevBuf<srt_triangle> triangles;
 	DevBuf<srt_material> materials;
 	DevBuf<float> wtris;
@@ -167,7 +171,8 @@ int srt_create(int width, int height, int device_index, srt_tracer **out) {
 	t->canvas_bytes = px * 16;
 	if ((e = t->argb.reserve(px * 4)) != hipSuccess) return bail("argb alloc", e);
 	if ((e = t->counters.reserve(SRT_CTR_COUNT)) != hipSuccess) return bail("counter alloc", e);
-	if ((e = t->shapes.reserve(1)) != hipSuccess || (e = t->loop_shapes.reserve(1)) != hipSuccess ||
+	if ((e = t->shapes.reserve(1)) != hipSuccess || (e = t->runs.reserve(1)) != hipSuccess ||
+	    (e = t->run_data.reserve(32)) != hipSuccess || (e = t->winners.reserve(1)) != hipSuccess ||
 	    (e = t->triangles.reserve(1)) != hipSuccess || (e = t->materials.reserve(1)) != hipSuccess ||
 	    (e = t->wtris.reserve(SRT_WTRI_FLOATS)) != hipSuccess || (e = t->wtri_offset.reserve(1)) != hipSuccess)
 		return bail("scene alloc", e);
@@ -189,7 +194,9 @@ void srt_destroy(srt_tracer *t) {
 	t->canvas_own.release();
 	t->argb.release();
 	t->shapes.release();
-	t->loop_shapes.release();
+	t->runs.release();
+	t->run_data.release();
+	t->winners.release();
 	t->triangles.release();
 	t->materials.release();
 	t->wtris.release();
@@ -227,35 +234,51 @@ int srt_update_scene(srt_tracer *t, const srt_shape *shapes, size_t n_shapes, co
 		return fail(t, SRT_ERR_INVALID, "srt_update_scene: NULL array with non-zero count");
 	if (n_shapes > 0x7fffffffu || n_triangles > 0xffffffffu) return fail(t, SRT_ERR_INVALID, "srt_update_scene: too many records");
 
-	// Host pass: loop records + world-triangle offsets. The reference would read out of
+	// Host pass: runs of same-type shapes in array order, their packed scalar-load records,
+	// per-shape winner records and world-triangle offsets. The reference would read out of
 	// bounds for a bad triangle range or material index; we refuse instead.
-	std::vector<LoopShape> loop(n_shapes ? n_shapes : 1);
+	std::vector<ShapeRun> runs;
+	std::vector<float> data; // packed, every run starts on a 16-dword boundary
+	std::vector<WinnerRec> winners(n_shapes ? n_shapes : 1);
 	std::vector<uint32_t> offs(n_shapes ? n_shapes : 1, 0u);
 	uint64_t total_wtris = 0, max_tris = 0;
 	int num_models = 0;
+	auto u2f = [](uint32_t u) {
+		float f;
+		memcpy(&f, &u, 4);
+		return f;
+	};
 	for (size_t i = 0; i < n_shapes; i++) {
 		const srt_shape &s = shapes[i];
-		LoopShape &l = loop[i];
-		memset(&l, 0, sizeof l);
-		l.type = s.type;
+		WinnerRec &wr = winners[i];
+		memset(&wr, 0, sizeof wr);
+		wr.type = s.type;
+		wr.material = s.material;
 		if (s.material >= 0 && (size_t)s.material >= n_materials) {
 			char buf[128];
 			snprintf(buf, sizeof buf, "srt_update_scene: shape %zu uses material %d but only %zu exist", i, s.material, n_materials);
 			return fail(t, SRT_ERR_INVALID, buf);
 		}
+		if (s.type != SRT_SHAPE_SPHERE && s.type != SRT_SHAPE_PLANE && s.type != SRT_SHAPE_MODEL) continue; // ignored, as render.cl:301-366
+		if (runs.empty() || runs.back().type != s.type || runs.back().first_shape + runs.back().count != i) {
+			while (data.size() % 16) data.push_back(0.0f);
+			ShapeRun r;
+			r.type = s.type;
+			r.first_shape = (uint32_t)i;
+			r.count = 0;
+			r.data_off = (uint32_t)data.size();
+			runs.push_back(r);
+		}
+		runs.back().count++;
 		if (s.type == SRT_SHAPE_SPHERE) {
-			l.f[0] = s.shape.sphere.position.x;
-			l.f[1] = s.shape.sphere.position.y;
-			l.f[2] = s.shape.sphere.position.z;
-			l.f[3] = s.shape.sphere.radius * s.shape.sphere.radius; // render.cl:187
+			const srt_sphere &sp = s.shape.sphere;
+			data.insert(data.end(), {sp.position.x, sp.position.y, sp.position.z, sp.radius * sp.radius}); // r*r as render.cl:187
+			wr.vx = sp.position.x, wr.vy = sp.position.y, wr.vz = sp.position.z, wr.w = sp.radius;
 		} else if (s.type == SRT_SHAPE_PLANE) {
-			l.f[0] = s.shape.plane.position.x;
-			l.f[1] = s.shape.plane.position.y;
-			l.f[2] = s.shape.plane.position.z;
-			l.f[3] = s.shape.plane.normal.x;
-			l.f[4] = s.shape.plane.normal.y;
-			l.f[5] = s.shape.plane.normal.z;
-		} else if (s.type == SRT_SHAPE_MODEL) {
+			const srt_plane &pl = s.shape.plane;
+			data.insert(data.end(), {pl.position.x, pl.position.y, pl.position.z, 0.0f, pl.normal.x, pl.normal.y, pl.normal.z, 0.0f});
+			wr.vx = pl.normal.x, wr.vy = pl.normal.y, wr.vz = pl.normal.z;
+		} else {
 			const srt_model &m = s.shape.model;
 			if ((uint64_t)m.triangle_index + m.num_triangles > n_triangles) {
 				char buf[160];
@@ -263,35 +286,37 @@ int srt_update_scene(srt_tracer *t, const srt_shape *shapes, size_t n_shapes, co
 				         m.triangle_index, m.triangle_index, m.num_triangles, n_triangles);
 				return fail(t, SRT_ERR_INVALID, buf);
 			}
-			l.f[0] = m.bounding_min.x;
-			l.f[1] = m.bounding_min.y;
-			l.f[2] = m.bounding_min.z;
-			l.f[3] = m.bounding_max.x;
-			l.f[4] = m.bounding_max.y;
-			l.f[5] = m.bounding_max.z;
 			if (total_wtris + m.num_triangles > 0xffffffffull) return fail(t, SRT_ERR_INVALID, "srt_update_scene: too many world triangles");
-			l.a = (uint32_t)total_wtris;
-			l.b = m.num_triangles;
+			data.insert(data.end(), {m.bounding_min.x, m.bounding_min.y, m.bounding_min.z, u2f((uint32_t)total_wtris), m.bounding_max.x,
+			                         m.bounding_max.y, m.bounding_max.z, u2f(m.num_triangles)});
+			wr.first_wtri = (uint32_t)total_wtris;
 			offs[i] = (uint32_t)total_wtris;
 			total_wtris += m.num_triangles;
 			if (m.num_triangles > max_tris) max_tris = m.num_triangles;
 			num_models++;
 		}
 	}
+	data.resize(data.size() + 32, 0.0f); // the kernel reads whole 64-byte blocks past a run's last record
+	while (data.size() % 16) data.push_back(0.0f);
 
 	SRT_HIP(t, hipSetDevice(t->device));
 	SRT_HIP(t, hipStreamSynchronize(t->stream)); // previous launches may still read the old scene
 	SRT_HIP(t, t->shapes.reserve(n_shapes));
-	SRT_HIP(t, t->loop_shapes.reserve(n_shapes));
+	SRT_HIP(t, t->runs.reserve(runs.size()));
+	SRT_HIP(t, t->run_data.reserve(data.size()));
+	SRT_HIP(t, t->winners.reserve(n_shapes));
 	SRT_HIP(t, t->wtri_offset.reserve(n_shapes));
 	SRT_HIP(t, t->triangles.reserve(n_triangles));
 	SRT_HIP(t, t->materials.reserve(n_materials));
 	SRT_HIP(t, t->wtris.reserve((size_t)total_wtris * SRT_WTRI_FLOATS + SRT_WTRI_FLOATS));
 	if (n_shapes) {
 		SRT_HIP(t, hipMemcpyAsync(t->shapes.ptr, shapes, n_shapes * sizeof(srt_shape), hipMemcpyHostToDevice, t->stream));
-		SRT_HIP(t, hipMemcpyAsync(t->loop_shapes.ptr, loop.data(), n_shapes * sizeof(LoopShape), hipMemcpyHostToDevice, t->stream));
+		SRT_HIP(t, hipMemcpyAsync(t->winners.ptr, winners.data(), n_shapes * sizeof(WinnerRec), hipMemcpyHostToDevice, t->stream));
 		SRT_HIP(t, hipMemcpyAsync(t->wtri_offset.ptr, offs.data(), n_shapes * sizeof(uint32_t), hipMemcpyHostToDevice, t->stream));
 	}
+	if (!runs.empty())
+		SRT_HIP(t, hipMemcpyAsync(t->runs.ptr, runs.data(), runs.size() * sizeof(ShapeRun), hipMemcpyHostToDevice, t->stream));
+	SRT_HIP(t, hipMemcpyAsync(t->run_data.ptr, data.data(), data.size() * sizeof(float), hipMemcpyHostToDevice, t->stream));
 	if (n_triangles)
 		SRT_HIP(t, hipMemcpyAsync(t->triangles.ptr, triangles, n_triangles * sizeof(srt_triangle), hipMemcpyHostToDevice, t->stream));
 	if (n_materials)
@@ -317,6 +342,8 @@ int srt_update_scene(srt_tracer *t, const srt_shape *shapes, size_t n_shapes, co
 	t->sd = *scene;
 	t->sd.num_shapes = (int32_t)n_shapes; // src/tracer.cpp:94
 	t->num_models = num_models;
+	t->num_runs = (int)runs.size();
+	t->num_materials = n_materials;
 	t->scene_set = true;
 	return SRT_OK;
 }
@@ -342,7 +369,12 @@ int srt_trace(srt_tracer *t, const srt_render_data *options) {
 	} else {
 		memset(&p.sd, 0, sizeof p.sd); // kernel arg 1 never set: behave as the empty scene
 	}
-	p.loop_shapes = t->loop_shapes.ptr;
+	p.loop_shapes = nullptr;
+	p.runs = t->runs.ptr;
+	p.run_data = t->run_data.ptr;
+	p.winners = t->winners.ptr;
+	p.num_runs = t->scene_set ? t->num_runs : 0;
+	p.num_materials = t->scene_set ? (int32_t)t->num_materials : 0;
 	p.shapes = t->shapes.ptr;
 	p.triangles = t->triangles.ptr;
 	p.materials = t->materials.ptr;

@@ -207,3 +207,37 @@ def mixed_test_scene():
         R.plane(0, (0, 0, -7), (0, 0, 2.0)),  # un-normalised normal on purpose (render.cl:206-221)
     ]
     return _stack(shapes, R.SHAPE), tris, mats
+
+
+# ---- model files in the syntax the reference's loaders read (src/parser.cpp) ---------
+def write_stl(path, tris):
+    """Binary STL: 80-byte header, u32 count, 50-byte records (normal, v1, v2, v3, u16)."""
+    tris = R.as_records(tris, R.TRIANGLE)
+    rec = np.zeros(len(tris), np.dtype([("f", "<f4", (12,)), ("attr", "<u2")]))
+    rec["f"][:, 0:3] = tris["v"][:, 0]["normal"]
+    for c in range(3):
+        rec["f"][:, 3 + 3 * c:6 + 3 * c] = tris["v"][:, c]["pos"]
+    with open(path, "wb") as f:
+        f.write(b"srt synthetic mesh".ljust(80, b" "))
+        f.write(np.uint32(len(tris)).tobytes())
+        f.write(rec.tobytes())
+
+
+def write_obj(path, tris):
+    """Wavefront OBJ with `v`, `vn` and `f a//a b//b c//c` (one v/vn pair per corner, so
+    the loader's index handling is exercised without any vertex welding). %.9g
+    round-trips binary32 exactly."""
+    tris = R.as_records(tris, R.TRIANGLE)
+    with open(path, "w") as f:
+        f.write("# srt synthetic mesh\ns off\n")
+        for t in tris:
+            for c in range(3):
+                p = t["v"][c]["pos"]
+                f.write("v %.9g %.9g %.9g\n" % (p[0], p[1], p[2]))
+        for t in tris:
+            for c in range(3):
+                n = t["v"][c]["normal"]
+                f.write("vn %.9g %.9g %.9g\n" % (n[0], n[1], n[2]))
+        for i in range(len(tris)):
+            a = 3 * i + 1
+            f.write("f %d//%d %d//%d %d//%d\n" % (a, a, a + 1, a + 1, a + 2, a + 2))

@@ -1,0 +1,111 @@
+"""The C++ host mirror (simple-raytracer_amd/host/*.hpp: Tracer / Shape / Material /
+Box / Model / parser) driven by tools/srt_headless.cpp the way the reference's
+src/main.cpp drives its own classes. CPU tests cover scene construction and the
+STL/OBJ/PPM formats; the GPU test renders through `Tracer` and checks the oracle."""
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import bits_equal
+from simple_raytracer_amd import records as R, scenes as S
+
+
+@pytest.fixture(scope="module")
+def headless():
+    from simple_raytracer_amd import build
+    return str(build.build_headless())
+
+
+def _load(prefix):
+    return (np.fromfile(prefix + ".shapes.bin", R.SHAPE), np.fromfile(prefix + ".tris.bin", R.TRIANGLE),
+            np.fromfile(prefix + ".mats.bin", R.MATERIAL))
+
+
+def test_cxx_scene_construction_matches_python_builder(headless, tmp_path):
+    prefix = str(tmp_path / "s")
+    subprocess.run([headless, "--scene", "spheres", "--parse-only", "--dump", prefix], check=True)
+    shapes, tris, mats = _load(prefix)
+    s2, t2, m2 = S.sphere_scene()
+    assert len(shapes) == 7 and len(tris) == 12 and len(mats) == 7
+    for name in R.MATERIAL.names:
+        assert np.array_equal(mats[name], m2[name]), name
+    assert np.array_equal(tris["v"]["pos"], t2["v"]["pos"]) and np.array_equal(tris["v"]["normal"], t2["v"]["normal"])
+    assert np.array_equal(shapes["type"], s2["type"]) and np.array_equal(shapes["material"], s2["material"])
+    pl, sp = shapes["type"] == 1, shapes["type"] == 0
+    assert np.array_equal(shapes["plane_position"][pl], s2["plane_position"][pl])
+    assert np.array_equal(shapes["plane_normal"][pl], s2["plane_normal"][pl])
+    assert np.array_equal(shapes["sphere_position"][sp], s2["sphere_position"][sp])
+    assert np.array_equal(shapes["sphere_radius"][sp], s2["sphere_radius"][sp])
+
+
+def test_stl_and_obj_loaders_round_trip(headless, tmp_path):
+    smooth = S.blob_mesh(10, 11, seed=3, smooth=True)
+    flat = S.blob_mesh(8, 7, seed=5, smooth=False)
+    obj, stl = tmp_path / "m.obj", tmp_path / "m.stl"
+    S.write_obj(obj, smooth)
+    S.write_stl(stl, flat)
+    prefix = str(tmp_path / "p")
+    subprocess.run([headless, "--scene", "meshes", "--obj", str(obj), "--stl", str(stl), "--parse-only", "--dump", prefix], check=True)
+    shapes, tris, mats = _load(prefix)
+    assert len(tris) == 12 + len(smooth) + len(flat)
+    got_s = tris[12:12 + len(smooth)]
+    got_f = tris[12 + len(smooth):]
+    assert np.array_equal(got_s["v"]["pos"], smooth["v"]["pos"])
+    # `vn` is re-normalised by the loader (src/parser.cpp:84): equal to ~1 ulp, unit length
+    assert np.allclose(got_s["v"]["normal"], smooth["v"]["normal"], atol=2e-7)
+    assert np.array_equal(got_f["v"]["pos"], flat["v"]["pos"])
+    assert np.array_equal(got_f["v"]["normal"], flat["v"]["normal"])  # STL facet normal copied verbatim x3
+    # the two Model shapes reference the right ranges and their world AABB encloses the transformed vertices
+    models = shapes[shapes["type"] == 2]
+    assert [int(m["num_triangles"]) for m in models] == [12, len(smooth), len(flat)]
+    assert [int(m["triangle_index"]) for m in models[1:]] == [12, 12 + len(smooth)]
+    for m in models[1:]:
+        pos = tris["v"]["pos"][int(m["triangle_index"]):int(m["triangle_index"]) + int(m["num_triangles"])].reshape(-1, 3)
+        world = R.transform_points(m["transform"], pos, 1.0)
+        assert np.array_equal(m["bounding_min"], world.min(axis=0)) and np.array_equal(m["bounding_max"], world.max(axis=0))
+
+
+def test_obj_variants_and_errors(headless, tmp_path):
+    p = tmp_path / "v.obj"
+    p.write_text("# comment\nv 0 0 0\nv 1 0 0\nv 0 1 0\nv 0 0 1\nvn 0 0 2\nvt 0.5 0.5\ns 1\n"
+                 "f 1/1/1 2/1/1 3/1/1\nf 1 2 4\nf -4//-1 -3//-1 -2//-1\n")
+    prefix = str(tmp_path / "v")
+    subprocess.run([headless, "--scene", "empty", "--obj", str(p), "--parse-only", "--dump", prefix], check=True)
+    _, tris, _ = _load(prefix)
+    t = tris[12:]
+    assert len(t) == 3
+    assert np.array_equal(t[0]["v"]["normal"], np.tile([0, 0, 1], (3, 1)))      # vn normalised
+    assert np.array_equal(t[1]["v"]["normal"], np.tile([0, -1, 0], (3, 1)))     # no vn: geometric normal
+    assert np.array_equal(t[2]["v"]["pos"], t[0]["v"]["pos"])                   # negative = from the end
+    r = subprocess.run([headless, "--scene", "empty", "--obj", str(tmp_path / "missing.obj"), "--parse-only"], capture_output=True, text=True)
+    assert r.returncode == 3 and "Inexistant file" in r.stderr                 # the GUI's wording, interface.cpp:277-290
+    bad = tmp_path / "bad.obj"
+    bad.write_text("v 0 0 0\nf 1 2 3\n")
+    assert subprocess.run([headless, "--scene", "empty", "--obj", str(bad), "--parse-only"], capture_output=True).returncode == 3
+
+
+@pytest.mark.gpu
+def test_cxx_tracer_renders_like_oracle_and_writes_ppm(headless, tmp_path, oracle, sky):
+    obj = tmp_path / "m.obj"
+    S.write_obj(obj, S.blob_mesh(10, 11, seed=3, smooth=True))
+    prefix, ppm = str(tmp_path / "r"), tmp_path / "frame.ppm"
+    w, h, spp, frames = 96, 64, 3, 2
+    subprocess.run([headless, "--scene", "meshes", "--obj", str(obj), "--width", str(w), "--height", str(h), "--spp", str(spp),
+                    "--frames", str(frames), "--time", "4242", "--out", str(ppm), "--dump", prefix], check=True)
+    shapes, tris, mats = _load(prefix)
+    rd = np.fromfile(prefix + ".rd.bin", R.RENDER_DATA)[0]
+    sd = np.fromfile(prefix + ".sd.bin", R.SCENE_DATA)[0]
+    canvas = np.fromfile(prefix + ".canvas.bin", np.float32).reshape(h, w, 4)
+    argb = np.fromfile(prefix + ".argb.bin", np.uint8).reshape(h, w, 4)
+    want = None
+    for f in range(frames):
+        r = rd.copy()
+        r["time"] = np.uint32(4242 + 7919 * f)
+        want = oracle.render(r, sd, shapes, tris, mats, sky, canvas=want)
+    assert bits_equal(canvas, want)
+    assert np.array_equal(argb, oracle.average(frames, want))
+    data = ppm.read_bytes()
+    head = f"P6 {w} {h} 255\n".encode()
+    assert data.startswith(head) and len(data) == len(head) + w * h * 3
+    assert np.array_equal(np.frombuffer(data[len(head):], np.uint8).reshape(h, w, 3), argb[..., 1:])

@@ -32,8 +32,21 @@ def stale():
     return any(d.stat().st_mtime > t for d in deps)
 
 
+def build_variant(name, extra_flags):
+    """A/B experiments: the same sources with extra -D flags -> lib/variants/<name>/libsrt_hip.so."""
+    out = LIBDIR / "variants" / name
+    out.mkdir(parents=True, exist_ok=True)
+    cmd = [hipcc(), *FLAGS, *extra_flags, "-shared", "-o", str(out / "libsrt_hip.so")] + [str(CSRC / s) for s in SOURCES]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("hipcc failed:\n" + r.stdout + r.stderr)
+    return out / "libsrt_hip.so"
+
+
 def build_hip(force=False, verbose=False, extra_flags=()):
     """Compile the HIP library if sources are newer than the .so. Returns its path."""
+    if os.environ.get("SRT_LIB"):
+        return Path(os.environ["SRT_LIB"])
     if not force and not stale():
         return LIB
     LIBDIR.mkdir(exist_ok=True)

@@ -205,12 +205,45 @@ DM_FN double dm_exp_d(double t) {
 	return p * sc;
 }
 
-/* pow(x, y), float in / float out, computed in double: <1 ulp. Follows the
- * OpenCL/C99 special-case table for the cases a renderer can reach. */
+/* Exponent of the integer fast path of dm_powf: n in 1..32 when y is exactly that
+ * integer, else 0. (The kernel's exponent is the wave-uniform SceneData.sun_focus,
+ * 25.0 by default, src/main.cpp:123, so the choice of path never diverges.) */
+DM_FN int dm_pow_small_int(float y) {
+	if (!(y >= 1.0f && y <= 32.0f)) return 0;
+	int n = (int)y;
+	return ((float)n == y) ? n : 0;
+}
+
+/* x^n, 1 <= n <= 32, by binary exponentiation in DOUBLE (at most 5 squarings + 4
+ * products, relative error < 1e-15), rounded once to float: < 0.5000001 ulp. Signs,
+ * zeros, inf and NaN come out right by plain IEEE multiplication; overflow/underflow
+ * happen in the final conversion (|x|^32 stays far inside the double range). */
+DM_FN float dm_powi(float x, int n) {
+	double b = (double)x, r = b;
+	int first = 1;
+	unsigned un = (unsigned)n;
+	while (un) {
+		if (un & 1u) {
+			r = first ? b : r * b;
+			first = 0;
+		}
+		un >>= 1;
+		if (un) b = b * b;
+	}
+	return (float)r;
+}
+
+/* pow(x, y), float in / float out. Small positive integer y: dm_powi. Otherwise
+ * computed in double: <1 ulp. Follows the OpenCL/C99 special-case table for the cases
+ * a renderer can reach. */
 DM_FN float dm_powf(float x, float y) {
 	if (y == 0.0f) return 1.0f;
 	if (x == 1.0f) return 1.0f;
 	if (x != x || y != y) return DM_NAN_F;
+	{
+		int n = dm_pow_small_int(y);
+		if (n) return dm_powi(x, n);
+	}
 	uint32_t uy = dm_f2u(y);
 	float ay = dm_fabs(y);
 	/* integer-ness / parity of y */
@@ -264,33 +297,10 @@ DM_FN double dm_pown_d(double x, int n) {
 	return n < 0 ? 1.0 / result : result;
 }
 
-/* atan(t) for t in [0,1], double, abs error < 1e-13 */
-DM_FN double dm_atan01_d(double t) {
-	double off = 0.0;
-	if (t > 0.41421356237309503) {
-		t = (t - 1.0) / (t + 1.0);
-		off = 0.7853981633974483;
-	}
-	double z = t * t;
-	double p = 1.0 / 29.0;
-	p = -(p * z) + 1.0 / 27.0;
-	p = -(p * z) + 1.0 / 25.0;
-	p = -(p * z) + 1.0 / 23.0;
-	p = -(p * z) + 1.0 / 21.0;
-	p = -(p * z) + 1.0 / 19.0;
-	p = -(p * z) + 1.0 / 17.0;
-	p = -(p * z) + 1.0 / 15.0;
-	p = -(p * z) + 1.0 / 13.0;
-	p = -(p * z) + 1.0 / 11.0;
-	p = -(p * z) + 1.0 / 9.0;
-	p = -(p * z) + 1.0 / 7.0;
-	p = -(p * z) + 1.0 / 5.0;
-	p = -(p * z) + 1.0 / 3.0;
-	p = -(p * z) + 1.0;
-	return off + t * p;
-}
-
-/* atan2pi(y, x) = atan2(y, x) / pi, OpenCL C 7.5.1 edge cases. */
+/* atan2pi(y, x) = atan2(y, x) / pi, OpenCL C 7.5.1 edge cases. Float only:
+ * a = min/max in [0,1] (one IEEE division), atan(a)/pi = a * P(a^2) with a degree-9
+ * near-minimax P (tools/gen_detmath_coeffs.py), then exact-constant quadrant folds
+ * 0.5 - t and 1 - t. Measured max error < 3 ulp against libm (bound: 6). */
 DM_FN float dm_atan2pif(float y, float x) {
 	if (x != x || y != y) return DM_NAN_F;
 	uint32_t sy = dm_f2u(y) >> 31, sx = dm_f2u(x) >> 31;
@@ -305,13 +315,24 @@ DM_FN float dm_atan2pif(float y, float x) {
 	} else if (ax == DM_INF_F) {
 		r = sx ? 1.0f : 0.0f;
 	} else {
-		double dx = (double)ax, dy = (double)ay;
-		int swap = dy > dx;
-		double t = swap ? dx / dy : dy / dx;
-		double a = dm_atan01_d(t);
-		if (swap) a = 1.5707963267948966 - a;
-		if (sx) a = 3.141592653589793 - a;
-		r = (float)(a * 0.3183098861837907);
+		int swap = ay > ax;
+		float mn = swap ? ax : ay, mx = swap ? ay : ax;
+		float a = mn / mx;
+		float z = a * a;
+		float p = -5.414992338e-04f;
+		p = p * z + 3.338322509e-03f;
+		p = p * z + -9.661298245e-03f;
+		p = p * z + 1.817217097e-02f;
+		p = p * z + -2.657799982e-02f;
+		p = p * z + 3.479872271e-02f;
+		p = p * z + -4.539104179e-02f;
+		p = p * z + 6.365585327e-02f;
+		p = p * z + -1.061031148e-01f;
+		p = p * z + 3.183098733e-01f;
+		float t = a * p;
+		if (swap) t = 0.5f - t;
+		if (sx) t = 1.0f - t;
+		r = t;
 	}
 	return sy ? -r : r;
 }

@@ -212,8 +212,12 @@ __device__ __forceinline__ f3 sky_box(const TraceParams &p, f3 dir) {
 // ---------------------------------------------------------------------------------
 // Trace kernel. 64-thread workgroups = one wave = one 8x8 pixel tile.
 // ---------------------------------------------------------------------------------
+#ifndef SRT_TRACE_WAVES_PER_SIMD
+#define SRT_TRACE_WAVES_PER_SIMD 4 // register budget: 512 / 4 = 128 VGPRs per lane
+#endif
+
 template <bool COUNT_TRIS, bool USE_LDS>
-__global__ __launch_bounds__(64) void srt_trace_kernel(const TraceParams p) {
+__global__ __launch_bounds__(64, SRT_TRACE_WAVES_PER_SIMD) void srt_trace_kernel(const TraceParams p) {
 	extern __shared__ float4 lds[]; // [2*n_shapes] winner records, then [4*n_materials] materials
 	const int width = p.rd.width;
 	const int tiles_x = (width + 7) >> 3;

@@ -68,3 +68,12 @@ def log_tail(z):
     return (mp.log((1 + s) / (1 - s)) - 2 * s) / (s * z)
 
 show("L", cheb_fit(log_tail, mp.mpf(0), smax ** 2 * mp.mpf("1.02"), 3))
+
+# atan(a)/pi = a * (A0 + A1 z + ... + A9 z^9), z = a^2 in [0,1]
+def atanpi_tail(z):
+    if z == 0:
+        return 1 / mp.pi
+    s = mp.sqrt(z)
+    return mp.atan(s) / (mp.pi * s)
+
+show("A", cheb_fit(atanpi_tail, mp.mpf(0), mp.mpf(1), 9))

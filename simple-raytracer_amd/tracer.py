@@ -14,7 +14,11 @@ import numpy as np
 from . import records as R
 
 PKG = Path(__file__).resolve().parent
-LIB_PATH = PKG / "lib" / "libsrt_hip.so"
+import os  # noqa: E402
+
+# SRT_LIB selects an alternative build of the SAME library (A/B experiments); there is
+# still no non-HIP path.
+LIB_PATH = Path(os.environ["SRT_LIB"]) if os.environ.get("SRT_LIB") else PKG / "lib" / "libsrt_hip.so"
 
 # every symbol include/srt_abi.h declares
 ABI_SYMBOLS = [

@@ -176,6 +176,12 @@ class Oracle:
         self._f("sky_box")(_p(sd), _p(sky), C.c_int(sky.shape[1]), C.c_int(sky.shape[0]), _p(d), _p(out))
         return out
 
+    def math_checksums(self, stride):
+        out = (C.c_uint64 * 8)()
+        self.lib.orc_math_checksums.restype = None
+        self.lib.orc_math_checksums(C.c_uint32(stride), out)
+        return [int(v) for v in out]
+
     def aces(self, rgb):
         a = np.ascontiguousarray(rgb, np.float32)
         out = np.zeros(3, np.float32)

@@ -540,3 +540,28 @@ float orc_log(float x) { return dm_logf(x); }
 float orc_pow(float x, float y) { return dm_powf(x, y); }
 float orc_atan2pi(float y, float x) { return dm_atan2pif(y, x); }
 int orc_num_counters(void) { return ORC_C_COUNT; }
+
+/* Host-side twin of the device self-test (srt_selftest_math): sums of result bit
+ * patterns of detmath over r = 0, stride, ... ; out[3..7] as in include/srt_abi.h. */
+static inline uint64_t canon_bits(float a) { return (a != a) ? 0x7fc00000ull : (uint64_t)dm_f2u(a); }
+void orc_math_checksums(uint32_t stride, uint64_t *out8) {
+	uint64_t s_log = 0, s_cos = 0, s_sqrt = 0, s_atan = 0, s_pow = 0;
+	const uint64_t total = (0x100000000ull + stride - 1) / stride;
+#pragma omp parallel for reduction(+ : s_log, s_cos, s_sqrt, s_atan, s_pow) schedule(static)
+	for (uint64_t i = 0; i < total; i++) {
+		const uint32_t r = (uint32_t)(i * stride);
+		const float u = (float)r / 4294967296.0f;
+		const float th = 6.28318548f * u;
+		s_log += canon_bits(dm_logf(u));
+		s_cos += canon_bits(dm_cosf(th));
+		s_sqrt += canon_bits(dm_sqrtf(u));
+		s_atan += canon_bits(dm_atan2pif(u - 0.5f, 0.37f - u));
+		s_pow += canon_bits(dm_powf(u, 25.0f));
+	}
+	for (int k = 0; k < 8; k++) out8[k] = 0;
+	out8[3] = s_log;
+	out8[4] = s_cos;
+	out8[5] = s_sqrt;
+	out8[6] = s_atan;
+	out8[7] = s_pow;
+}

@@ -17,7 +17,8 @@ while args:
     else:
         name, _, flags = a.partition("=")
         variants[name] = flags.split() if flags else []
-libs = {n: str(B.build_variant(n, f)) for n, f in variants.items()}
+# "name=@path/to/libsrt_hip.so" uses a prebuilt library (e.g. an older revision built before gpurun)
+libs = {n: (f[0][1:] if f and f[0].startswith("@") else str(B.build_variant(n, f))) for n, f in variants.items()}
 res = {n: [] for n in variants}
 for r in range(rounds):
     for n, lib in libs.items():

@@ -99,5 +99,6 @@ struct ResolveParams {
 void srt_launch_trace(TraceParams p, bool count_triangles, void *stream);
 void srt_launch_prepass(const PrepassParams &p, uint64_t total_wtris, void *stream);
 void srt_launch_resolve(const ResolveParams &p, void *stream);
+void srt_launch_selftest(unsigned long long *out8, uint32_t stride, void *stream);
 
 #endif

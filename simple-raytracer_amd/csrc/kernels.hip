@@ -45,7 +45,30 @@ __device__ __forceinline__ float dot3(f3 a, f3 b) { return (a.x * b.x + a.y * b.
 __device__ __forceinline__ f3 cross3(f3 a, f3 b) {
 	return mk(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
 }
-__device__ __forceinline__ f3 normalize3(f3 a) { return a / dm_sqrtf(dot3(a, a)); }
+// Correctly rounded sqrt. hipcc's own expansion (v_sqrt_f32 + two FMA residual tests
+// against the neighbouring floats) spends 7 more instructions on 2^32 pre/post scaling
+// for inputs below 2^-96 and on a zero/inf class fix-up. For x = 0, x >= 2^-96, inf, NaN
+// and x <= -2^-96 the unscaled core already returns the IEEE result (see DESIGN.md
+// "Numerics"), so only 0 < |x| < 2^-96 takes the compiler's full sequence (v_sqrt_f32
+// flushes denormal inputs: sqrt(-denormal) must be NaN, not -0). Verified against
+// __builtin_sqrtf on all 2^32 bit patterns by srt_selftest_math.
+__device__ __forceinline__ float sqrt_ieee(float x) {
+#ifndef SRT_NO_FAST_SQRT
+	const uint32_t mag = dm_f2u(x) & 0x7fffffffu;
+	if (__builtin_expect((mag - 1u) < 0x0f7fffffu, 0)) return __builtin_sqrtf(x); // 0 < |x| < 2^-96
+	float s = __builtin_amdgcn_sqrtf(x); // within 1 ulp
+	const uint32_t si = dm_f2u(s);
+	float down = dm_u2f(si - 1u), up = dm_u2f(si + 1u);
+	float vp = __builtin_fmaf(-down, s, x);
+	float vs = __builtin_fmaf(-up, s, x);
+	s = (vp <= 0.0f) ? down : s;
+	s = (vs > 0.0f) ? up : s;
+	return s;
+#else
+	return dm_sqrtf(x);
+#endif
+}
+__device__ __forceinline__ f3 normalize3(f3 a) { return a / sqrt_ieee(dot3(a, a)); }
 __device__ __forceinline__ f3 mix3(f3 x, f3 y, float a) {
 	return mk(dm_mix(x.x, y.x, a), dm_mix(x.y, y.y, a), dm_mix(x.z, y.z, a));
 }
@@ -70,17 +93,57 @@ __device__ __forceinline__ float random_float(uint32_t &seed) {
 	return (float)r * 2.3283064365386963e-10f; // exact: division by 2^32
 }
 
+// dm_logf restricted to what random_float can return: 0 or a normal float in
+// [2^-32, 1]. Same operations on that domain as detmath.h's dm_logf (whose negative /
+// subnormal / inf / NaN handling can never trigger here), so the same bits.
+__device__ __forceinline__ float log_unit(float u) {
+	const float LN2_HI = 6.93138123e-01f, LN2_LO = 9.05800061e-06f;
+	const float L0 = 6.66666687e-01f, L1 = 4.00001287e-01f, L2 = 2.85499692e-01f, L3 = 2.33534276e-01f;
+	uint32_t ix = dm_f2u(u);
+	int k = (int)(ix >> 23) - 127;
+	ix &= 0x007fffffu;
+	uint32_t i = (ix + 0x4afb20u) & 0x00800000u;
+	float x = dm_u2f(ix | (i ^ 0x3f800000u));
+	k += (int)(i >> 23);
+	float f = x - 1.0f;
+	float s = f / (2.0f + f);
+	float z = s * s;
+	float R = z * (L0 + z * (L1 + z * (L2 + z * L3)));
+	float hfsq = (0.5f * f) * f;
+	float dk = (float)k;
+	float r = dk * LN2_HI + (f - (hfsq - (s * (hfsq + R) + dk * LN2_LO)));
+	return u == 0.0f ? -DM_INF_F : r;
+}
+
+// dm_cosf restricted to finite x in [0, 8): detmath.h's range / NaN guard dropped.
+__device__ __forceinline__ float cos_2pi(float x) {
+	int k = (int)(x * 6.36619747e-01f + 0.5f);
+	float fk = (float)k;
+	float r = x - fk * 1.5703125f;
+	r = r - fk * 4.83751297e-04f;
+	r = r - fk * 7.54953362e-08f;
+	r = r - fk * 2.56334407e-12f;
+	float z = r * r;
+	int odd = k & 1;
+	float c0 = odd ? -1.66666642e-01f : 4.16666642e-02f;
+	float c1 = odd ? 8.33272468e-03f : -1.38882792e-03f;
+	float c2 = odd ? -1.95828557e-04f : 2.45428964e-05f;
+	float p = c0 + z * (c1 + z * c2);
+	float s_res = r + (r * z) * p;
+	float c_res = ((z * z) * p - 0.5f * z) + 1.0f;
+	float res = odd ? s_res : c_res;
+	return (((k + 1) >> 1) & 1) ? -res : res;
+}
+
 // Box-Muller, theta drawn first (render.cl:150-154)
 __device__ __forceinline__ float random_normal(uint32_t &seed) {
 	float theta = 6.28318548f * random_float(seed);
-	float rho = dm_sqrtf(-2.0f * dm_logf(random_float(seed)));
-	return rho * dm_cosf(theta);
+	float rho = sqrt_ieee(-2.0f * log_unit(random_float(seed)));
+	return rho * cos_2pi(theta);
 }
 
-// fp64 Schlick (render.cl:173-178)
-__device__ __forceinline__ float schlick(float mu, float cos_theta) {
-	float r0 = (float)((1.0 - (double)mu) / (1.0 + (double)mu));
-	r0 = r0 * r0;
+// fp64 Schlick (render.cl:173-178); r0 = ((1-mu)/(1+mu))^2 is a per-material constant
+__device__ __forceinline__ float schlick(float r0, float cos_theta) {
 	double x = 1.0 - (double)cos_theta;
 	double x5 = x * ((x * x) * (x * x)); // dm_pown_d(x, 5)
 	return (float)((double)r0 + (1.0 - (double)r0) * x5);
@@ -100,7 +163,7 @@ __device__ __forceinline__ void test_sphere(float cx, float cy, float cz, float 
 	float b = dot3(L, dir);
 	float c = dot3(L, L) - r2;
 	float disc = b * b - c;
-	float sq = dm_sqrtf(disc);
+	float sq = sqrt_ieee(disc);
 	float t = b - sq;
 	if (t < 0.0f) t = b + sq;
 	bool hit = !(disc < 0.0f) && !(t < 0.0f);
@@ -138,21 +201,34 @@ __device__ __forceinline__ bool test_aabb(float lx, float ly, float lz, float hx
 	return t0 < t1;
 }
 
-// Moller-Trumbore (render.cl:243-275) over the pre-pass triangles [first, first+count)
+// One Moller-Trumbore test (render.cl:243-275) against a pre-pass triangle in SGPRs.
+//
+// The reference rejects at `u < 0 || u > 1` with u = fl(fl(1/a) * sh); that needs an IEEE
+// reciprocal (11 instructions) before the first reject. For brute force over 10^5
+// triangles almost every lane of almost every wave fails that test, so a conservative,
+// division-free pre-reject runs first. With sh = dot(s, h):
+//   R1  a == 0                                            (the reference's own test)
+//   R2  |sh| > 1.001 |a|              =>  |u| > 1         (u > 1 or u < 0: miss either way)
+//   R3  sh*a < 0 and |sh| >= 0.001 |a| =>  u < 0, not an underflow to -0
+// Each implies the reference's miss for every finite, infinite or denormal a (margins of
+// 2^-10 dwarf the 2^-22 worst-case relative error of fl(1/a)*sh; NaNs compare false and
+// fall through). Lanes not rejected run the reference's exact sequence; the wave skips
+// it when no lane is left (s_cbranch_execz). Results are therefore bit-identical.
 template <bool COUNT_TRIS>
-__device__ __forceinline__ void test_triangles(const float *__restrict__ wtris, uint32_t first, uint32_t count, f3 org, f3 dir, int idx,
-                                               float &tmin, int &best, uint32_t &best_tri, uint32_t &n_tri_u) {
-	for (uint32_t j = 0; j < count; j++) {
-		const float *__restrict__ w = wtris + (size_t)(first + j) * SRT_WTRI_FLOATS;
-		f3 v0 = mk(w[0], w[1], w[2]);
-		f3 e1 = mk(w[3], w[4], w[5]);
-		f3 e2 = mk(w[6], w[7], w[8]);
-		f3 h = cross3(dir, e2);
-		float a = dot3(e1, h);
+__device__ __forceinline__ void test_triangle(float v0x, float v0y, float v0z, float e1x, float e1y, float e1z, float e2x, float e2y,
+                                              float e2z, f3 org, f3 dir, int idx, uint32_t j, float &tmin, int &best, uint32_t &best_tri,
+                                              uint32_t &n_tri_u) {
+	f3 e1 = mk(e1x, e1y, e1z), e2 = mk(e2x, e2y, e2z);
+	f3 h = cross3(dir, e2);
+	float a = dot3(e1, h);
+	f3 sv = mk(org.x - v0x, org.y - v0y, org.z - v0z);
+	float sh = dot3(sv, h);
+	float aa = dm_fabs(a), ash = dm_fabs(sh);
+	bool reject = (a == 0.0f) || (ash > aa * 1.001f) || ((sh * a < 0.0f) && (ash >= aa * 0.001f));
+	if (!reject) {
 		float f = 1.0f / a;
-		f3 sv = org - v0;
-		float u = f * dot3(sv, h);
-		bool ok = !(a == 0.0f) && !(u < 0.0f || u > 1.0f);
+		float u = f * sh;
+		bool ok = !(u < 0.0f || u > 1.0f);
 		if (COUNT_TRIS) n_tri_u += ok ? 1u : 0u;
 		f3 q = cross3(sv, e1);
 		float v = f * dot3(dir, q);
@@ -163,6 +239,29 @@ __device__ __forceinline__ void test_triangles(const float *__restrict__ wtris, 
 			tmin = t;
 			best = idx;
 			best_tri = j;
+		}
+	}
+}
+
+// 4 pre-pass triangles = 36 dwords = 144 bytes, 16-byte aligned (each model's block of
+// world triangles starts on a multiple of 4 and is padded with all-zero triangles,
+// which fail R1): three wide scalar loads per 4 tests.
+struct alignas(16) Tri4 {
+	float v[36];
+};
+
+template <bool COUNT_TRIS>
+__device__ __forceinline__ void test_triangles(const float *__restrict__ wtris, uint32_t first, uint32_t count, f3 org, f3 dir, int idx,
+                                               float &tmin, int &best, uint32_t &best_tri, uint32_t &n_tri_u) {
+	const Tri4 *__restrict__ blk = reinterpret_cast<const Tri4 *>(wtris + (size_t)first * SRT_WTRI_FLOATS);
+	const uint32_t nblk = (count + 3u) >> 2;
+	for (uint32_t b = 0; b < nblk; b++) {
+		const Tri4 t = blk[b];
+#pragma unroll
+		for (int k = 0; k < 4; k++) {
+			const float *w = t.v + 9 * k;
+			test_triangle<COUNT_TRIS>(w[0], w[1], w[2], w[3], w[4], w[5], w[6], w[7], w[8], org, dir, idx, 4u * b + (uint32_t)k, tmin, best,
+			                          best_tri, n_tri_u);
 		}
 	}
 }
@@ -213,7 +312,7 @@ __device__ __forceinline__ f3 sky_box(const TraceParams &p, f3 dir) {
 // Trace kernel. 64-thread workgroups = one wave = one 8x8 pixel tile.
 // ---------------------------------------------------------------------------------
 #ifndef SRT_TRACE_WAVES_PER_SIMD
-#define SRT_TRACE_WAVES_PER_SIMD 4 // register budget: 512 / 4 = 128 VGPRs per lane
+#define SRT_TRACE_WAVES_PER_SIMD 5 // register budget: 96 VGPRs per lane; +4 % over 4 waves (A/B, profiles/)
 #endif
 
 template <bool COUNT_TRIS, bool USE_LDS>
@@ -402,17 +501,19 @@ __global__ __launch_bounds__(64, SRT_TRACE_WAVES_PER_SIMD) void srt_trace_kernel
 							mask = mask * mix3(mcolor, mk(1.0f, 1.0f, 1.0f), is_specular ? 1.0f : 0.0f);
 						} else {
 							f3 in_dir = reflect3(rough_dir, nrm);
-							float mu = front ? 1.0f / ior : ior;
+							// 1/ior and both Schlick r0 values come precomputed with the material (srt_update_scene)
+							float mu = front ? m1.z : ior;
+							float r0 = front ? m1.w : mc.w;
 							float cos_theta = dm_min(1.0f, dot3(in_dir, neg(nrm)));
-							float sin_theta = dm_sqrtf(1.0f - cos_theta * cos_theta);
+							float sin_theta = sqrt_ieee(1.0f - cos_theta * cos_theta);
 							bool reflected = mu * sin_theta > 1.0f;
-							if (!reflected) reflected = schlick(mu, cos_theta) > random_float(seed); // short-circuit ||
+							if (!reflected) reflected = schlick(r0, cos_theta) > random_float(seed); // short-circuit ||
 							if (reflected) {
 								dir = rough_dir;
 							} else {
 								f3 out_perp = (in_dir + nrm * cos_theta) * mu;
 								float lsq = (out_perp.x * out_perp.x + out_perp.y * out_perp.y) + out_perp.z * out_perp.z;
-								f3 out_parallel = nrm * (-dm_sqrtf(dm_fabs(1.0f - lsq)));
+								f3 out_parallel = nrm * (-sqrt_ieee(dm_fabs(1.0f - lsq)));
 								dir = out_perp + out_parallel;
 								mask = mask * mcolor;
 							}
@@ -516,12 +617,61 @@ __global__ __launch_bounds__(256) void srt_resolve_kernel(const ResolveParams p)
 	const float n = (float)p.num_steps;
 	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < p.num_pixels; i += gridDim.x * blockDim.x) {
 		float4 c = canvas[i];
-		float r = dm_sqrtf(aces1(c.x / n));
-		float g = dm_sqrtf(aces1(c.y / n));
-		float b = dm_sqrtf(aces1(c.z / n));
+		float r = sqrt_ieee(aces1(c.x / n));
+		float g = sqrt_ieee(aces1(c.y / n));
+		float b = sqrt_ieee(aces1(c.z / n));
 		// memory order A, R, G, B (little endian word)
 		out[i] = 255u | (to_uchar(r * 255.0f) << 8) | (to_uchar(g * 255.0f) << 16) | (to_uchar(b * 255.0f) << 24);
 	}
+}
+
+// ---------------------------------------------------------------------------------
+// Math self-test: the kernel-local specialisations against their generic definitions,
+// and checksums of the generic ones for comparison with the HOST build of detmath.h.
+// r walks 0, stride, 2*stride, ... over all 2^32 values; u = r * 2^-32 is exactly what
+// random_float returns for that r.
+//   out[0] sqrt_ieee(bits r) != __builtin_sqrtf   out[1] log_unit(u) != dm_logf(u)
+//   out[2] cos_2pi(t) != dm_cosf(t), t = 2pi*u    out[3] sum of bits of dm_logf(u)
+//   out[4] sum of bits of dm_cosf(t)              out[5] sum of bits of sqrt(u)
+//   out[6] sum of bits of dm_atan2pif(u - 0.5, 0.37 - u)   out[7] sum of bits of dm_powf(u, 25)
+// ---------------------------------------------------------------------------------
+namespace {
+__device__ __forceinline__ bool same_float(float a, float b) { return (a != a && b != b) || dm_f2u(a) == dm_f2u(b); }
+__device__ __forceinline__ unsigned long long canon_bits(float a) { return (a != a) ? 0x7fc00000ull : (unsigned long long)dm_f2u(a); }
+} // namespace
+
+__global__ __launch_bounds__(256) void srt_selftest_kernel(unsigned long long *out, uint32_t stride) {
+	unsigned long long bad_sqrt = 0, bad_log = 0, bad_cos = 0, s_log = 0, s_cos = 0, s_sqrt = 0, s_atan = 0, s_pow = 0;
+	const unsigned long long total = (0x100000000ull + stride - 1) / stride;
+	for (unsigned long long i = blockIdx.x * (unsigned long long)blockDim.x + threadIdx.x; i < total;
+	     i += (unsigned long long)gridDim.x * blockDim.x) {
+		const uint32_t r = (uint32_t)(i * stride);
+		const float asbits = dm_u2f(r);
+		bad_sqrt += same_float(sqrt_ieee(asbits), __builtin_sqrtf(asbits)) ? 0 : 1;
+		const float u = (float)r * 2.3283064365386963e-10f;
+		const float lg = dm_logf(u);
+		bad_log += same_float(log_unit(u), lg) ? 0 : 1;
+		const float th = 6.28318548f * u;
+		const float cs = dm_cosf(th);
+		bad_cos += same_float(cos_2pi(th), cs) ? 0 : 1;
+		s_log += canon_bits(lg);
+		s_cos += canon_bits(cs);
+		s_sqrt += canon_bits(dm_sqrtf(u));
+		s_atan += canon_bits(dm_atan2pif(u - 0.5f, 0.37f - u));
+		s_pow += canon_bits(dm_powf(u, 25.0f));
+	}
+	atomicAdd(&out[0], bad_sqrt);
+	atomicAdd(&out[1], bad_log);
+	atomicAdd(&out[2], bad_cos);
+	atomicAdd(&out[3], s_log);
+	atomicAdd(&out[4], s_cos);
+	atomicAdd(&out[5], s_sqrt);
+	atomicAdd(&out[6], s_atan);
+	atomicAdd(&out[7], s_pow);
+}
+
+void srt_launch_selftest(unsigned long long *out, uint32_t stride, void *stream) {
+	hipLaunchKernelGGL(srt_selftest_kernel, dim3(2048), dim3(256), 0, (hipStream_t)stream, out, stride);
 }
 
 // ---------------------------------------------------------------------------------

@@ -291,7 +291,7 @@ int srt_update_scene(srt_tracer *t, const srt_shape *shapes, size_t n_shapes, co
 			                         m.bounding_max.y, m.bounding_max.z, u2f(m.num_triangles)});
 			wr.first_wtri = (uint32_t)total_wtris;
 			offs[i] = (uint32_t)total_wtris;
-			total_wtris += m.num_triangles;
+			total_wtris += ((uint64_t)m.num_triangles + 3u) & ~3ull; // blocks of 4; the tail stays all-zero (never hit)
 			if (m.num_triangles > max_tris) max_tris = m.num_triangles;
 			num_models++;
 		}
@@ -319,10 +319,28 @@ int srt_update_scene(srt_tracer *t, const srt_shape *shapes, size_t n_shapes, co
 	SRT_HIP(t, hipMemcpyAsync(t->run_data.ptr, data.data(), data.size() * sizeof(float), hipMemcpyHostToDevice, t->stream));
 	if (n_triangles)
 		SRT_HIP(t, hipMemcpyAsync(t->triangles.ptr, triangles, n_triangles * sizeof(srt_triangle), hipMemcpyHostToDevice, t->stream));
+	// Device-side material table = the caller's records with three per-material constants
+	// parked in padding floats, so the glass branch does no division at all:
+	//   _pad[0] (offset 24) = 1.0f / refraction_index                      (render.cl:442, front face)
+	//   _pad[1] (offset 28) = Schlick r0 for mu = 1/refraction_index       (render.cl:174-175, fp64 then float)
+	//   color._pad (offset 44) = Schlick r0 for mu = refraction_index      (back face)
+	// Same IEEE operations the kernel would run per hit, hence the same bits.
+	std::vector<srt_material> dev_mats(materials, materials + n_materials);
+	auto schlick_r0 = [](float mu) {
+		float r0 = (float)((1.0 - (double)mu) / (1.0 + (double)mu));
+		return r0 * r0;
+	};
+	for (auto &m : dev_mats) {
+		const float inv_ior = 1.0f / m.refraction_index;
+		m._pad[0] = inv_ior;
+		m._pad[1] = schlick_r0(inv_ior);
+		m.color._pad = schlick_r0(m.refraction_index);
+	}
 	if (n_materials)
-		SRT_HIP(t, hipMemcpyAsync(t->materials.ptr, materials, n_materials * sizeof(srt_material), hipMemcpyHostToDevice, t->stream));
+		SRT_HIP(t, hipMemcpyAsync(t->materials.ptr, dev_mats.data(), n_materials * sizeof(srt_material), hipMemcpyHostToDevice, t->stream));
 
 	if (num_models > 0 && total_wtris > 0) {
+		SRT_HIP(t, hipMemsetAsync(t->wtris.ptr, 0, ((size_t)total_wtris * SRT_WTRI_FLOATS + SRT_WTRI_FLOATS) * sizeof(float), t->stream));
 		// blockIdx.y = shape index; launch in slabs of 65535 shapes
 		for (size_t base = 0; base < n_shapes; base += 65535) {
 			PrepassParams pp;
@@ -561,6 +579,26 @@ int srt_set_partition(srt_tracer *t, int rank, int world, int rows_per_block) {
 	t->owned_rows = srt_partition_owned_rows(t->height, rank, world, rows_per_block);
 	SRT_HIP(t, hipMemsetAsync(t->argb.ptr, 0, t->argb.cap, t->stream));
 	return clear_canvas_impl(t);
+}
+
+int srt_selftest_math(srt_tracer *t, uint32_t stride, uint64_t out[8]) {
+	if (!t) return SRT_ERR_INVALID;
+	if (!out || stride == 0) return fail(t, SRT_ERR_INVALID, "srt_selftest_math: bad arguments");
+	SRT_HIP(t, hipSetDevice(t->device));
+	unsigned long long *d = nullptr;
+	SRT_HIP(t, hipMalloc(reinterpret_cast<void **>(&d), 8 * sizeof(unsigned long long)));
+	hipError_t e = hipMemsetAsync(d, 0, 8 * sizeof(unsigned long long), t->stream);
+	if (e == hipSuccess) {
+		srt_launch_selftest(d, stride, t->stream);
+		e = hipGetLastError();
+	}
+	unsigned long long h[8] = {0};
+	if (e == hipSuccess) e = hipMemcpyAsync(h, d, sizeof h, hipMemcpyDeviceToHost, t->stream);
+	if (e == hipSuccess) e = hipStreamSynchronize(t->stream);
+	(void)hipFree(d);
+	if (e != hipSuccess) return fail(t, SRT_ERR_HIP, std::string("srt_selftest_math: ") + hipGetErrorString(e));
+	for (int i = 0; i < 8; i++) out[i] = h[i];
+	return SRT_OK;
 }
 
 /* test hook: build with triangle counters (instrumented kernel variant) */

@@ -27,7 +27,7 @@ ABI_SYMBOLS = [
     "srt_get_counters", "srt_set_count_triangles", "srt_reset_counters", "srt_last_kernel_ms",
     "srt_device_buffers", "srt_bind_canvas", "srt_bind_stream", "srt_set_partition",
     "srt_partition_owned_rows", "srt_partition_padded_rows", "srt_partition_global_row",
-    "srt_partition_unpermute", "srt_version",
+    "srt_partition_unpermute", "srt_selftest_math", "srt_version",
 ]
 
 
@@ -81,6 +81,7 @@ def load_library():
     lib.srt_partition_padded_rows.argtypes = [i, i, i]
     lib.srt_partition_global_row.argtypes = [i, i, i, i, i]
     lib.srt_partition_unpermute.argtypes = [vp, vp, i, i, i, sz]
+    lib.srt_selftest_math.argtypes = [vp, C.c_uint32, C.POINTER(C.c_uint64)]
     lib.srt_version.restype = C.c_char_p
     _lib = lib
     return lib
@@ -184,6 +185,11 @@ class Tracer:
 
     def count_triangles(self, enable=True):
         self._check(self.lib.srt_set_count_triangles(self._h, 1 if enable else 0))
+
+    def selftest_math(self, stride=1):
+        out = (C.c_uint64 * 8)()
+        self._check(self.lib.srt_selftest_math(self._h, stride, out))
+        return [int(v) for v in out]
 
     def last_kernel_ms(self):
         a, b = C.c_float(), C.c_float()

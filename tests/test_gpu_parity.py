@@ -191,3 +191,20 @@ def test_oracle_agrees_on_rows_of_the_1080p_frame(T, sky, oracle):
     want = oracle.render(rd, g["sd"], shapes, tris, mats, sky, rows=(536, 544))
     assert bits_equal(rows, want[536:544])
     t.close()
+
+
+def test_device_math_equals_host_math(T, oracle):
+    """Bit-for-bit determinism of csrc/detmath.h across x86-64 and gfx950, and of the
+    kernel-local sqrt/log/cos specialisations against their generic definitions.
+    Mismatch counts: EVERY one of the 2^32 RNG outputs (stride 1). Checksums vs the host
+    build: every 61st (the CPU side takes a few seconds)."""
+    t = T.Tracer(8, 8)
+    full = t.selftest_math(1)
+    assert full[0] == 0, f"sqrt_ieee differs from IEEE sqrt on {full[0]} of 2^32 bit patterns"
+    assert full[1] == 0, f"log_unit differs from dm_logf on {full[1]} RNG outputs"
+    assert full[2] == 0, f"cos_2pi differs from dm_cosf on {full[2]} RNG outputs"
+    dev = t.selftest_math(61)
+    host = oracle.math_checksums(61)
+    assert dev[:3] == [0, 0, 0]
+    assert dev[3:] == host[3:], (dev, host)
+    t.close()

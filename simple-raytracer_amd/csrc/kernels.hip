@@ -315,7 +315,10 @@ __device__ __forceinline__ f3 sky_box(const TraceParams &p, f3 dir) {
 #define SRT_TRACE_WAVES_PER_SIMD 5 // register budget: 96 VGPRs per lane; +4 % over 4 waves (A/B, profiles/)
 #endif
 
-template <bool COUNT_TRIS, bool USE_LDS>
+// HAS_MODELS = false compiles every AABB / triangle / mesh-normal path out: scenes of
+// spheres and planes (BASELINE configs 0, 1, 3) get a leaner kernel (fewer registers, no
+// spills, smaller code); the host picks the instantiation from the scene.
+template <bool COUNT_TRIS, bool USE_LDS, bool HAS_MODELS>
 __global__ __launch_bounds__(64, SRT_TRACE_WAVES_PER_SIMD) void srt_trace_kernel(const TraceParams p) {
 	extern __shared__ float4 lds[]; // [2*n_shapes] winner records, then [4*n_materials] materials
 	const int width = p.rd.width;
@@ -375,7 +378,7 @@ __global__ __launch_bounds__(64, SRT_TRACE_WAVES_PER_SIMD) void srt_trace_kernel
 			int best = -1;
 			uint32_t best_tri = 0;
 			f3 inv = mk(0.f, 0.f, 0.f);
-			if (p.num_models > 0) inv = mk(1.0f / dir.x, 1.0f / dir.y, 1.0f / dir.z);
+			if (HAS_MODELS) inv = mk(1.0f / dir.x, 1.0f / dir.y, 1.0f / dir.z);
 
 			for (int r = 0; r < p.num_runs; r++) {
 				const ShapeRun run = runs[r];
@@ -396,7 +399,7 @@ __global__ __launch_bounds__(64, SRT_TRACE_WAVES_PER_SIMD) void srt_trace_kernel
 						test_plane(b.v[0], b.v[1], b.v[2], b.v[4], b.v[5], b.v[6], org, dir, base + (int)k, tmin, best);
 						if (k + 1 < cnt) test_plane(b.v[8], b.v[9], b.v[10], b.v[12], b.v[13], b.v[14], org, dir, base + (int)k + 1, tmin, best);
 					}
-				} else if (run.type == SRT_SHAPE_MODEL) {
+				} else if (HAS_MODELS && run.type == SRT_SHAPE_MODEL) {
 					for (uint32_t k = 0; k < cnt; k += 2) {
 						const Blk16 b = *reinterpret_cast<const Blk16 *>(d + 8 * k);
 						if (test_aabb(b.v[0], b.v[1], b.v[2], b.v[4], b.v[5], b.v[6], org, inv, tmin)) {
@@ -440,7 +443,7 @@ __global__ __launch_bounds__(64, SRT_TRACE_WAVES_PER_SIMD) void srt_trace_kernel
 					nrm = (pos - wv) / ww;
 				} else if (type == SRT_SHAPE_PLANE) {
 					nrm = wv;
-				} else {
+				} else if (HAS_MODELS) {
 					const srt_model *__restrict__ m = &p.shapes[best].shape.model;
 					const float *__restrict__ w = wtris + (size_t)(first_wtri + best_tri) * SRT_WTRI_FLOATS;
 					f3 v0 = mk(w[0], w[1], w[2]);
@@ -687,12 +690,17 @@ void srt_launch_trace(TraceParams p, bool count_triangles, void *stream) {
 	const bool use_lds = need <= 8192;
 	p.lds_bytes = use_lds ? (uint32_t)need : 0u;
 	hipStream_t st = (hipStream_t)stream;
-	if (use_lds) {
-		if (count_triangles) hipLaunchKernelGGL((srt_trace_kernel<true, true>), grid, block, need, st, p);
-		else hipLaunchKernelGGL((srt_trace_kernel<false, true>), grid, block, need, st, p);
+	const bool models = p.num_models > 0;
+	auto go = [&](auto kernel, size_t lds) { hipLaunchKernelGGL(kernel, grid, block, lds, st, p); };
+	if (!models) {
+		if (use_lds) go(srt_trace_kernel<false, true, false>, need);
+		else go(srt_trace_kernel<false, false, false>, 0);
+	} else if (use_lds) {
+		if (count_triangles) go(srt_trace_kernel<true, true, true>, need);
+		else go(srt_trace_kernel<false, true, true>, need);
 	} else {
-		if (count_triangles) hipLaunchKernelGGL((srt_trace_kernel<true, false>), grid, block, 0, st, p);
-		else hipLaunchKernelGGL((srt_trace_kernel<false, false>), grid, block, 0, st, p);
+		if (count_triangles) go(srt_trace_kernel<true, false, true>, 0);
+		else go(srt_trace_kernel<false, false, true>, 0);
 	}
 }
 

@@ -81,7 +81,8 @@ def load_library():
     lib.srt_partition_padded_rows.argtypes = [i, i, i]
     lib.srt_partition_global_row.argtypes = [i, i, i, i, i]
     lib.srt_partition_unpermute.argtypes = [vp, vp, i, i, i, sz]
-    lib.srt_selftest_math.argtypes = [vp, C.c_uint32, C.POINTER(C.c_uint64)]
+    if hasattr(lib, "srt_selftest_math"):  # absent only in older A/B builds selected through SRT_LIB
+        lib.srt_selftest_math.argtypes = [vp, C.c_uint32, C.POINTER(C.c_uint64)]
     lib.srt_version.restype = C.c_char_p
     _lib = lib
     return lib

@@ -243,26 +243,35 @@ __device__ __forceinline__ void test_triangle(float v0x, float v0y, float v0z, f
 	}
 }
 
-// 4 pre-pass triangles = 36 dwords = 144 bytes, 16-byte aligned (each model's block of
-// world triangles starts on a multiple of 4 and is padded with all-zero triangles,
-// which fail R1): three wide scalar loads per 4 tests.
-struct alignas(16) Tri4 {
-	float v[36];
+// Each model's block of world triangles starts on a multiple of 4 and is padded to a
+// multiple of 4 with all-zero triangles (which fail R1), so the loop below needs no tail
+// handling. Triangles are fetched two at a time (18 dwords: s_load_dwordx16 + x2) into
+// TWO alternating SGPR sets: the load of the next pair is issued before the current
+// pair is tested, which hides the scalar-cache / L2 latency that a single buffer would
+// expose once per block (the loop is otherwise latency-bound at low occupancy).
+struct alignas(8) Tri2 {
+	float v[18];
 };
+
+template <bool COUNT_TRIS>
+__device__ __forceinline__ void test_pair(const Tri2 &t, f3 org, f3 dir, int idx, uint32_t j, float &tmin, int &best, uint32_t &best_tri,
+                                          uint32_t &n_tri_u) {
+	test_triangle<COUNT_TRIS>(t.v[0], t.v[1], t.v[2], t.v[3], t.v[4], t.v[5], t.v[6], t.v[7], t.v[8], org, dir, idx, j, tmin, best, best_tri, n_tri_u);
+	test_triangle<COUNT_TRIS>(t.v[9], t.v[10], t.v[11], t.v[12], t.v[13], t.v[14], t.v[15], t.v[16], t.v[17], org, dir, idx, j + 1u, tmin, best,
+	                          best_tri, n_tri_u);
+}
 
 template <bool COUNT_TRIS>
 __device__ __forceinline__ void test_triangles(const float *__restrict__ wtris, uint32_t first, uint32_t count, f3 org, f3 dir, int idx,
                                                float &tmin, int &best, uint32_t &best_tri, uint32_t &n_tri_u) {
-	const Tri4 *__restrict__ blk = reinterpret_cast<const Tri4 *>(wtris + (size_t)first * SRT_WTRI_FLOATS);
-	const uint32_t nblk = (count + 3u) >> 2;
-	for (uint32_t b = 0; b < nblk; b++) {
-		const Tri4 t = blk[b];
-#pragma unroll
-		for (int k = 0; k < 4; k++) {
-			const float *w = t.v + 9 * k;
-			test_triangle<COUNT_TRIS>(w[0], w[1], w[2], w[3], w[4], w[5], w[6], w[7], w[8], org, dir, idx, 4u * b + (uint32_t)k, tmin, best,
-			                          best_tri, n_tri_u);
-		}
+	const Tri2 *__restrict__ blk = reinterpret_cast<const Tri2 *>(wtris + (size_t)first * SRT_WTRI_FLOATS);
+	const uint32_t npair = ((count + 3u) >> 2) << 1; // pairs, always even
+	Tri2 a = blk[0];
+	for (uint32_t b = 0; b < npair; b += 2) {
+		const Tri2 c = blk[b + 1]; // in flight while `a` is tested
+		test_pair<COUNT_TRIS>(a, org, dir, idx, 2u * b, tmin, best, best_tri, n_tri_u);
+		a = blk[b + 2];            // in flight while `c` is tested (one pair of slack is allocated past the end)
+		test_pair<COUNT_TRIS>(c, org, dir, idx, 2u * b + 2u, tmin, best, best_tri, n_tri_u);
 	}
 }
 

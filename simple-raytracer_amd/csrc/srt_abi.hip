@@ -174,7 +174,7 @@ int srt_create(int width, int height, int device_index, srt_tracer **out) {
 	if ((e = t->shapes.reserve(1)) != hipSuccess || (e = t->runs.reserve(1)) != hipSuccess ||
 	    (e = t->run_data.reserve(32)) != hipSuccess || (e = t->winners.reserve(1)) != hipSuccess ||
 	    (e = t->triangles.reserve(1)) != hipSuccess || (e = t->materials.reserve(1)) != hipSuccess ||
-	    (e = t->wtris.reserve(SRT_WTRI_FLOATS)) != hipSuccess || (e = t->wtri_offset.reserve(1)) != hipSuccess)
+	    (e = t->wtris.reserve(SRT_WTRI_FLOATS + 64)) != hipSuccess || (e = t->wtri_offset.reserve(1)) != hipSuccess)
 		return bail("scene alloc", e);
 	if ((e = hipEventCreate(&t->ev_t0)) != hipSuccess || (e = hipEventCreate(&t->ev_t1)) != hipSuccess ||
 	    (e = hipEventCreate(&t->ev_r0)) != hipSuccess || (e = hipEventCreate(&t->ev_r1)) != hipSuccess)
@@ -308,7 +308,7 @@ int srt_update_scene(srt_tracer *t, const srt_shape *shapes, size_t n_shapes, co
 	SRT_HIP(t, t->wtri_offset.reserve(n_shapes));
 	SRT_HIP(t, t->triangles.reserve(n_triangles));
 	SRT_HIP(t, t->materials.reserve(n_materials));
-	SRT_HIP(t, t->wtris.reserve((size_t)total_wtris * SRT_WTRI_FLOATS + SRT_WTRI_FLOATS));
+	SRT_HIP(t, t->wtris.reserve((size_t)total_wtris * SRT_WTRI_FLOATS + 64)); // + slack for the loop's look-ahead pair
 	if (n_shapes) {
 		SRT_HIP(t, hipMemcpyAsync(t->shapes.ptr, shapes, n_shapes * sizeof(srt_shape), hipMemcpyHostToDevice, t->stream));
 		SRT_HIP(t, hipMemcpyAsync(t->winners.ptr, winners.data(), n_shapes * sizeof(WinnerRec), hipMemcpyHostToDevice, t->stream));
@@ -340,7 +340,7 @@ int srt_update_scene(srt_tracer *t, const srt_shape *shapes, size_t n_shapes, co
 		SRT_HIP(t, hipMemcpyAsync(t->materials.ptr, dev_mats.data(), n_materials * sizeof(srt_material), hipMemcpyHostToDevice, t->stream));
 
 	if (num_models > 0 && total_wtris > 0) {
-		SRT_HIP(t, hipMemsetAsync(t->wtris.ptr, 0, ((size_t)total_wtris * SRT_WTRI_FLOATS + SRT_WTRI_FLOATS) * sizeof(float), t->stream));
+		SRT_HIP(t, hipMemsetAsync(t->wtris.ptr, 0, ((size_t)total_wtris * SRT_WTRI_FLOATS + 64) * sizeof(float), t->stream));
 		// blockIdx.y = shape index; launch in slabs of 65535 shapes
 		for (size_t base = 0; base < n_shapes; base += 65535) {
 			PrepassParams pp;

@@ -110,6 +110,8 @@ def main():
     ap.add_argument("--spp", type=int, default=0, help="override samples per pixel (development only; makes the line non-comparable)")
     ap.add_argument("--rows-per-block", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="gloo = REHEARSAL ONLY on a box with fewer GPUs than ranks: ranks share cuda:0 and the gather is staged through host memory")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -122,11 +124,17 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
     B.build_hip()
+    rehearsal = args.backend == "gloo"
+    if rehearsal:
+        local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if rehearsal:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     builder, w, h, spp, nb, desc = WORKLOADS[args.workload]
     if args.spp:
@@ -159,10 +167,19 @@ def main():
         t.clear_canvas()
         t.trace()
         if world > 1:
-            dist.gather(canvas_t, gather_bufs, dst=0)  # the ONE collective of the path (RCCL over xGMI)
+            if rehearsal:
+                host = canvas_t.cpu()
+                bufs = [torch.empty_like(host) for _ in range(world)] if rank == 0 else None
+                dist.gather(host, bufs, dst=0)
+                if rank == 0:
+                    for dst_buf, src in zip(gather_bufs, bufs):
+                        dst_buf.copy_(src)
+            else:
+                dist.gather(canvas_t, gather_bufs, dst=0)  # the ONE collective of the path (RCCL over xGMI)
             if rank == 0:
                 full = torch.cat(gather_bufs, dim=0).index_select(0, unperm)
                 t.resolve_external(full.data_ptr(), w * h, 1, argb_t.data_ptr())
+                step.full = full
         elif rank == 0:
             t.resolve_external(canvas_t.data_ptr(), w * h, 1, argb_t.data_ptr())
         if record:
@@ -176,6 +193,8 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
+    step.full = None
+
     for _ in range(args.warmup):
         step(False)
     fence()
@@ -188,14 +207,29 @@ def main():
     elapsed = time.perf_counter() - t0
 
     c = t.counters()
-    stats = torch.tensor([elapsed, float(np.mean(trace_ms)) if trace_ms else 0.0], dtype=torch.float64, device=dev)
-    cnt = torch.tensor([c["rays"], c["paths"], c["sky"], c["nan_pixels"]], dtype=torch.int64, device=dev)
+    red_dev = torch.device("cpu") if rehearsal else dev
+    stats = torch.tensor([elapsed, float(np.mean(trace_ms)) if trace_ms else 0.0], dtype=torch.float64, device=red_dev)
+    cnt = torch.tensor([c["rays"], c["paths"], c["sky"], c["nan_pixels"]], dtype=torch.int64, device=red_dev)
     if world > 1:
         dist.all_reduce(stats, op=dist.ReduceOp.MAX)
         dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
     elapsed_max, trace_ms_max = float(stats[0]), float(stats[1])
     rays, paths, nsky, nan_px = (int(v) for v in cnt.tolist())
 
+    check = None
+    if rank == 0 and os.environ.get("SRT_BENCH_CHECK") and world > 1:
+        # rehearsal aid: the gathered, unpermuted canvas must equal a single-handle render bit for bit
+        ref_t = T.Tracer(w, h, device=local_rank)
+        ref_t.set_skybox(sky)
+        ref_t.options, ref_t.scene_data = t.options.copy(), t.scene_data.copy()
+        ref_t.update_scene(shapes, tris, mats)
+        ref_t.clear_canvas()
+        ref_t.trace()
+        want = ref_t.read_canvas()
+        got = step.full.cpu().numpy()
+        nan_w, nan_g = np.isnan(want), np.isnan(got)
+        check = bool(np.array_equal(nan_w, nan_g) and np.array_equal(want.view(np.uint32)[~nan_w], got.view(np.uint32)[~nan_g]))
+        ref_t.close()
     if rank == 0:
         steps = max(args.steps, 1)
         per = {"rays": rays // steps, "paths": paths // steps, "sky": nsky // steps, "tri_tests": 0, "tri_pass_u": 0}
@@ -248,6 +282,8 @@ def main():
                         "frac": round(nbytes / world / kt / HBM_PEAK, 6), "algorithmic_bytes_per_launch": int(nbytes // world)},
             },
         }
+        if check is not None:
+            line["gathered_equals_single_gpu"] = check
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.workload, sky)
         print(json.dumps(line), flush=True)

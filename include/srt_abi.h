@@ -93,6 +93,13 @@ int srt_synchronize(srt_tracer *t);
 int srt_resolve_external(srt_tracer *t, const void *device_canvas, uint32_t num_pixels, uint32_t ticks_stopped,
                          void *device_argb);
 
+/* Upper bound in bytes for the per-path radiance buffer (12 B per (pixel, sample) of a
+ * sample batch). A dispatch whose paths do not fit is run as several batches of samples
+ * with the ordered per-pixel sum carried across them: results are identical, only
+ * slower. 0 (default) = half of the free HBM at the first srt_trace, at most 96 GiB; the
+ * environment variable SRT_RADIANCE_BUDGET_MB overrides that default. */
+int srt_set_radiance_budget(srt_tracer *t, size_t bytes);
+
 /* ---- results / introspection ---------------------------------------------------- */
 
 /* Copies the accumulation canvas (owned rows, packed): n_owned_rows*width float4. */
@@ -104,9 +111,13 @@ int srt_get_counters(srt_tracer *t, srt_counters *out);
  * (one extra VALU op per triangle test); results are unchanged. Default off. */
 int srt_set_count_triangles(srt_tracer *t, int enable);
 int srt_reset_counters(srt_tracer *t);
-/* Device time of the most recent trace / resolve launch, from HIP events recorded on
- * the handle's stream around the kernel (milliseconds). Synchronises the stream. */
+/* Device time of the most recent srt_trace (trace kernel(s) + ordered reduction) and of
+ * the most recent resolve, from HIP events recorded on the handle's stream (milliseconds).
+ * Synchronises the stream. */
 int srt_last_kernel_ms(srt_tracer *t, float *trace_ms, float *resolve_ms);
+/* The same for srt_trace_kernel alone: first launch start to last launch end (with one
+ * sample batch, the usual case, exactly that one kernel; reductions excluded). */
+int srt_last_trace_kernel_ms(srt_tracer *t, float *kernel_ms);
 /* Device pointers of the handle's buffers, for zero-copy hand-off (e.g. to a
  * torch.distributed gather): canvas = owned_rows*width*16 B, argb = owned_rows*width*4 B. */
 int srt_device_buffers(srt_tracer *t, void **canvas, size_t *canvas_bytes, void **argb, size_t *argb_bytes);

@@ -55,7 +55,7 @@ static_assert(sizeof(WinnerRec) == 32, "WinnerRec 32 B");
  * bit-identical to what the reference recomputes per ray (render.cl:325-328,247-248). */
 #define SRT_WTRI_FLOATS 9
 
-enum { SRT_CTR_RAYS = 0, SRT_CTR_SKY, SRT_CTR_TRI, SRT_CTR_TRI_PASS_U, SRT_CTR_NAN, SRT_CTR_PATHS, SRT_CTR_COUNT };
+enum { SRT_CTR_RAYS = 0, SRT_CTR_SKY, SRT_CTR_TRI, SRT_CTR_TRI_PASS_U, SRT_CTR_NAN, SRT_CTR_PATHS, SRT_CTR_QUEUE, SRT_CTR_COUNT };
 
 struct TraceParams {
 	srt_render_data rd;
@@ -73,8 +73,15 @@ struct TraceParams {
 	const srt_material *materials;
 	const float *wtris;
 	const float *sky; /* RGBA32F */
-	float *canvas;    /* float4 per owned pixel, packed rows */
+	float *canvas;    /* float4 per owned pixel, packed rows (written by the reduce kernel) */
+	float *radiance;  /* 3 floats per work-item of the current batch: [pixel][sample in batch] */
 	unsigned long long *counters;
+	unsigned long long *queue;       /* global work cursor (items), zeroed before every launch */
+	unsigned long long total_items;  /* owned pixels * batch_samples */
+	uint32_t batch_samples;          /* samples per pixel in this batch */
+	uint32_t first_sample;           /* sample index of the batch's first sample */
+	uint32_t job_items;              /* items a wave reserves per atomic */
+	uint32_t _pad1;
 	int32_t sky_w, sky_h;
 	int32_t num_models;
 	int32_t rank, world, rows_per_block, owned_rows;
@@ -89,6 +96,20 @@ struct PrepassParams {
 	uint32_t num_triangles; /* size of the triangle array, for bounds clamping */
 };
 
+/* Ordered reduction of a batch: per pixel, colour += radiance[pixel][k] for k in order
+ * (render.cl:518), carried across batches in `running`; the last batch divides by
+ * num_samples and adds into the canvas (render.cl:520-522). */
+struct ReduceParams {
+	const float *radiance;
+	float *running; /* float4 per pixel, only used when a dispatch needs more than one batch */
+	float *canvas;
+	unsigned long long *counters;
+	uint32_t num_pixels;
+	uint32_t batch_samples;
+	int32_t num_samples;
+	uint32_t first_batch, last_batch;
+};
+
 struct ResolveParams {
 	const float *canvas;
 	uint8_t *argb;
@@ -96,7 +117,9 @@ struct ResolveParams {
 	uint32_t num_pixels;
 };
 
-void srt_launch_trace(TraceParams p, bool count_triangles, void *stream);
+void srt_launch_trace(TraceParams p, bool count_triangles, int num_waves, void *stream);
+void srt_launch_reduce(const ReduceParams &p, void *stream);
+int srt_trace_waves_per_simd(void);
 void srt_launch_prepass(const PrepassParams &p, uint64_t total_wtris, void *stream);
 void srt_launch_resolve(const ResolveParams &p, void *stream);
 void srt_launch_selftest(unsigned long long *out8, uint32_t stride, void *stream);

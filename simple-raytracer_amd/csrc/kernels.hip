@@ -4,13 +4,15 @@
 // (/root/reference/src/render.cl:483-535 and the helpers :114-481); how they compute
 // it is CDNA4-first and shares no structure with that file:
 //
-//  * srt_trace_kernel: ONE LANE PER PIXEL, persistent over that pixel's samples. The
+//  * srt_trace_kernel: ONE WORK-ITEM PER (PIXEL, SAMPLE) PATH, persistent waves. The
 //    reference's three nested loops (samples x bounces x shapes) are flattened into a
-//    single loop over path SEGMENTS: a lane whose path ends (sky miss, bounce limit,
-//    show_normals) starts its next sample on the very next iteration instead of idling
-//    until the longest path of the wave ends; the wave leaves when a ballot shows no
-//    lane has samples left. Lane-private serial accumulation in sample order makes the
-//    canvas bit-identical to the reference's `color += trace(...)` (render.cl:518).
+//    single loop over path SEGMENTS; a lane whose path ends (sky miss, bounce limit,
+//    show_normals) pulls the next item of the wave's job in the same iteration (ballot +
+//    mbcnt compaction), waves pull jobs from one global cursor, so lanes stay busy until
+//    the whole dispatch is done and any slice of the frame fills the chip. Each path's
+//    radiance is written to HBM (12 B; 25 GB at 1920x1080x1024 spp, what 288 GB are for)
+//    and srt_reduce_kernel sums them per pixel in sample order, which keeps the canvas
+//    bit-identical to the reference's serial `color += trace(...)` (render.cl:518).
 //  * The shape loop index is wave-uniform, so shape records and world-space triangles
 //    arrive through SCALAR loads (s_load_dwordx*) into SGPRs and feed VALU ops as
 //    scalar operands: no per-lane loads, no LDS traffic and no VGPRs for scene data.
@@ -331,15 +333,7 @@ template <bool COUNT_TRIS, bool USE_LDS, bool HAS_MODELS>
 __global__ __launch_bounds__(64, SRT_TRACE_WAVES_PER_SIMD) void srt_trace_kernel(const TraceParams p) {
 	extern __shared__ float4 lds[]; // [2*n_shapes] winner records, then [4*n_materials] materials
 	const int width = p.rd.width;
-	const int tiles_x = (width + 7) >> 3;
-	const int tile = blockIdx.x;
 	const int lane = threadIdx.x;
-	const int px = (tile % tiles_x) * 8 + (lane & 7);
-	const int lrow = (tile / tiles_x) * 8 + (lane >> 3);
-	const bool valid = px < width && lrow < p.owned_rows;
-	const int py = global_row(lrow, p.rank, p.world, p.rows_per_block);
-	const uint32_t id = (uint32_t)px + (uint32_t)py * (uint32_t)width; // render.cl:488
-
 	const int ns = p.rd.num_samples;
 	const int nb = p.rd.num_bounces;
 	const int n_shapes = p.sd.num_shapes;
@@ -355,32 +349,83 @@ __global__ __launch_bounds__(64, SRT_TRACE_WAVES_PER_SIMD) void srt_trace_kernel
 		__syncthreads();
 	}
 
-	f3 sum = mk(0.f, 0.f, 0.f);
+	// ---- work distribution: one work-item = one (pixel, sample) path -------------------
+	// Items of this dispatch: item = q * batch_samples + k, q = packed owned pixel
+	// (row-major), sample = first_sample + k. Consecutive items are consecutive samples of
+	// one pixel, so the 64 lanes of a wave start out on (nearly) the same camera ray.
+	// Persistent waves reserve jobs of `job_items` items from ONE global cursor; a lane whose
+	// path ends takes the wave's next item in the same iteration (ballot + mbcnt), so every
+	// lane stays busy until the global queue is dry. Radiance goes to radiance[item];
+	// srt_reduce_kernel adds it up per pixel in sample order.
+	const unsigned long long total_items = p.total_items;
+	const uint32_t nbs = p.batch_samples;
+	unsigned long long job_cur = 0, job_end = 0, job_base = 0, job_q0 = 0; // wave-uniform
+	uint32_t job_k0 = 0;                                                   // job_base = job_q0 * nbs + job_k0
+	bool queue_dry = (total_items == 0);
+
 	f3 org = mk(0.f, 0.f, 0.f), dir = mk(0.f, 0.f, 0.f), mask = mk(1.f, 1.f, 1.f), color = mk(0.f, 0.f, 0.f);
 	uint32_t seed = 0;
-	int sample = 0, bounce = 0;
-	bool fresh = true;
-	bool alive = valid && ns > 0 && nb > 0;
-	uint32_t n_rays = 0, n_sky = 0, n_tri = 0, n_tri_u = 0;
+	unsigned long long item = 0;
+	int bounce = 0;
+	bool active = false;
+	uint32_t n_rays = 0, n_sky = 0, n_tri = 0, n_tri_u = 0, n_paths = 0;
 
-	// A path with num_bounces <= 0 never enters the bounce loop (render.cl:403): colour 0.
-	while (__any(alive)) {
-		if (alive) {
-			if (fresh) {
-				// ---- new camera path (render.cl:496-516) ----
-				seed = ((uint32_t)sample + id * (uint32_t)ns) * p.rd.time * 5304u;
-				float ndc_x = ((float)px + random_float(seed)) / (float)width;
-				float ndc_y = ((float)py + random_float(seed)) / (float)p.rd.height;
-				float sx = ((2.f * ndc_x - 1.f) * p.rd.aspect_ratio) * p.rd.fov_scale;
-				float sy = (1.f - 2.f * ndc_y) * p.rd.fov_scale;
-				org = mk(p.rd.camera_to_world[3].x, p.rd.camera_to_world[3].y, p.rd.camera_to_world[3].z);
-				dir = normalize3(mat_by_vec(p.rd.camera_to_world, mk(sx, sy, -1.0f), 0.0f));
-				mask = mk(1.f, 1.f, 1.f);
-				color = mk(0.f, 0.f, 0.f);
-				bounce = 0;
-				fresh = false;
+	for (;;) {
+		// ---- refill idle lanes -----------------------------------------------------------
+		const unsigned long long want = __ballot(!active);
+		if (want != 0ull && !queue_dry) {
+			if (job_cur == job_end) {
+				unsigned long long start = 0;
+				if (lane == 0) start = atomicAdd(p.queue, (unsigned long long)p.job_items);
+				start = (unsigned long long)__shfl((long long)start, 0);
+				if (start >= total_items) {
+					queue_dry = true;
+				} else {
+					job_cur = job_base = start;
+					job_end = start + p.job_items < total_items ? start + p.job_items : total_items;
+					job_q0 = start / nbs; // the only 64-bit division, once per job
+					job_k0 = (uint32_t)(start - job_q0 * nbs);
+				}
 			}
+			if (!queue_dry) {
+				const unsigned long long avail = job_end - job_cur;
+				const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(want >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)want, 0u));
+				const uint32_t nwant = (uint32_t)__popcll(want);
+				if (!active && rank < avail) {
+					// ---- new camera path (render.cl:488,496-516) ----
+					item = job_cur + rank;
+					const uint32_t off = job_k0 + (uint32_t)(item - job_base); // < nbs + job_items: 32-bit math from here
+					const uint32_t dq = off / nbs;
+					const unsigned long long q = job_q0 + dq;
+					const uint32_t sample = p.first_sample + (off - dq * nbs);
+					const uint32_t lrow = (uint32_t)(q / (uint32_t)width);
+					const int px = (int)(q - (unsigned long long)lrow * (uint32_t)width);
+					const int py = global_row((int)lrow, p.rank, p.world, p.rows_per_block);
+					const uint32_t id = (uint32_t)px + (uint32_t)py * (uint32_t)width;
+					seed = (sample + id * (uint32_t)ns) * p.rd.time * 5304u;
+					float ndc_x = ((float)px + random_float(seed)) / (float)width;
+					float ndc_y = ((float)py + random_float(seed)) / (float)p.rd.height;
+					float sx = ((2.f * ndc_x - 1.f) * p.rd.aspect_ratio) * p.rd.fov_scale;
+					float sy = (1.f - 2.f * ndc_y) * p.rd.fov_scale;
+					org = mk(p.rd.camera_to_world[3].x, p.rd.camera_to_world[3].y, p.rd.camera_to_world[3].z);
+					dir = normalize3(mat_by_vec(p.rd.camera_to_world, mk(sx, sy, -1.0f), 0.0f));
+					mask = mk(1.f, 1.f, 1.f);
+					color = mk(0.f, 0.f, 0.f);
+					bounce = 0;
+					active = true;
+					n_paths++;
+				}
+				job_cur += nwant < avail ? nwant : avail;
+			}
+		}
+		if (!__any(active)) {
+			if (queue_dry) break;
+			continue; // the job ran out mid-refill: fetch the next one
+		}
 
+		if (active) {
+			bool done = (nb <= 0); // render.cl:403: no bounce loop at all -> colour 0
+			if (!done) {
 			// ---- closest_intersection (render.cl:293-378), winner deferred ----
 			n_rays++;
 			float tmin = DM_INF_F;
@@ -475,7 +520,6 @@ __global__ __launch_bounds__(64, SRT_TRACE_WAVES_PER_SIMD) void srt_trace_kernel
 				nrm = nrm * (front ? 1.0f : -1.0f);
 			}
 
-			bool done;
 			if (material_index >= 0) {
 				if (p.rd.show_normals) {
 					color = mk(nrm.x * 0.5f + 0.5f, nrm.y * 0.5f + 0.5f, nrm.z * 0.5f + 0.5f); // render.cl:407-410
@@ -543,29 +587,20 @@ __global__ __launch_bounds__(64, SRT_TRACE_WAVES_PER_SIMD) void srt_trace_kernel
 				done = true;
 			}
 
+			} // !done
 			if (done) {
-				sum = sum + color; // serial, in sample order (render.cl:518)
-				sample++;
-				fresh = true;
-				alive = sample < ns;
+				float *__restrict__ out = p.radiance + item * 3ull;
+				out[0] = color.x;
+				out[1] = color.y;
+				out[2] = color.z;
+				active = false;
 			}
 		}
 	}
 
-	if (valid) {
-		f3 c = sum / (float)ns; // render.cl:520 (ns == 0 -> 0/0 = NaN, as the reference)
-		float4 *out = reinterpret_cast<float4 *>(p.canvas) + ((size_t)lrow * width + px);
-		float4 o = *out;
-		o.x += c.x;
-		o.y += c.y;
-		o.z += c.z;
-		*out = o; // render.cl:522
-		if (c.x != c.x || c.y != c.y || c.z != c.z) atomicAdd(&p.counters[SRT_CTR_NAN], 1ull);
-	}
-
 	// one atomic per wave and counter
 	unsigned long long r = n_rays, k = n_sky, t3 = n_tri, t4 = n_tri_u;
-	unsigned long long np = valid ? (unsigned long long)(ns > 0 ? ns : 0) : 0ull;
+	unsigned long long np = n_paths;
 	for (int off = 32; off > 0; off >>= 1) {
 		r += __shfl_down(r, off);
 		k += __shfl_down(k, off);
@@ -583,6 +618,51 @@ __global__ __launch_bounds__(64, SRT_TRACE_WAVES_PER_SIMD) void srt_trace_kernel
 			atomicAdd(&p.counters[SRT_CTR_TRI], t3);
 			atomicAdd(&p.counters[SRT_CTR_TRI_PASS_U], t4);
 		}
+	}
+}
+
+// ---------------------------------------------------------------------------------
+// Ordered reduction: lane = pixel, serial over the batch's samples in sample order, so
+// the float sums are the reference's `color += trace(...)` sequence bit for bit no matter
+// which wave traced which sample. 12 B per path in, 16 B RMW per pixel out: HBM-bound.
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void srt_reduce_kernel(const ReduceParams p) {
+	const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+	if (q >= p.num_pixels) return;
+	f3 c = mk(0.f, 0.f, 0.f);
+	float4 *run = reinterpret_cast<float4 *>(p.running) + q;
+	if (!p.first_batch) {
+		float4 v = *run;
+		c = mk(v.x, v.y, v.z);
+	}
+	const uint32_t n = p.batch_samples;
+	const float *__restrict__ r = p.radiance + (size_t)q * n * 3u;
+	uint32_t k = 0;
+	if ((n & 3u) == 0u) {
+		// 4 samples = 48 B = three aligned 16-byte loads; additions stay in sample order
+		const float4 *__restrict__ r4 = reinterpret_cast<const float4 *>(r);
+		for (; k < n; k += 4) {
+			const float4 a = r4[0], b = r4[1], d = r4[2];
+			r4 += 3;
+			c = c + mk(a.x, a.y, a.z);
+			c = c + mk(a.w, b.x, b.y);
+			c = c + mk(b.z, b.w, d.x);
+			c = c + mk(d.y, d.z, d.w);
+		}
+	} else {
+		for (; k < n; k++) c = c + mk(r[3 * k], r[3 * k + 1], r[3 * k + 2]);
+	}
+	if (p.last_batch) {
+		c = c / (float)p.num_samples; // render.cl:520 (num_samples == 0 -> 0/0 = NaN, as the reference)
+		float4 *out = reinterpret_cast<float4 *>(p.canvas) + q;
+		float4 o = *out;
+		o.x += c.x;
+		o.y += c.y;
+		o.z += c.z;
+		*out = o; // render.cl:522
+		if (c.x != c.x || c.y != c.y || c.z != c.z) atomicAdd(&p.counters[SRT_CTR_NAN], 1ull);
+	} else {
+		*run = make_float4(c.x, c.y, c.z, 0.f);
 	}
 }
 
@@ -689,12 +769,12 @@ void srt_launch_selftest(unsigned long long *out, uint32_t stride, void *stream)
 // ---------------------------------------------------------------------------------
 // launch wrappers (host)
 // ---------------------------------------------------------------------------------
-void srt_launch_trace(TraceParams p, bool count_triangles, void *stream) {
-	const int tiles_x = (p.rd.width + 7) / 8, tiles_y = (p.owned_rows + 7) / 8;
-	const long long tiles = (long long)tiles_x * tiles_y;
-	if (tiles <= 0) return;
-	dim3 grid((unsigned)tiles), block(64);
-	// winners + materials go to LDS when small enough not to cost occupancy (16 waves/CU x 8 KB < 160 KB)
+int srt_trace_waves_per_simd(void) { return SRT_TRACE_WAVES_PER_SIMD; }
+
+void srt_launch_trace(TraceParams p, bool count_triangles, int num_waves, void *stream) {
+	if (p.total_items == 0 || num_waves <= 0) return;
+	dim3 grid((unsigned)num_waves), block(64);
+	// winners + materials go to LDS when small enough not to cost occupancy (20 waves/CU x 8 KB = 160 KB)
 	const size_t need = (size_t)p.sd.num_shapes * sizeof(WinnerRec) + (size_t)p.num_materials * sizeof(srt_material);
 	const bool use_lds = need <= 8192;
 	p.lds_bytes = use_lds ? (uint32_t)need : 0u;
@@ -711,6 +791,11 @@ void srt_launch_trace(TraceParams p, bool count_triangles, void *stream) {
 		if (count_triangles) go(srt_trace_kernel<true, false, true>, 0);
 		else go(srt_trace_kernel<false, false, true>, 0);
 	}
+}
+
+void srt_launch_reduce(const ReduceParams &p, void *stream) {
+	if (p.num_pixels == 0) return;
+	hipLaunchKernelGGL(srt_reduce_kernel, dim3((p.num_pixels + 255) / 256), dim3(256), 0, (hipStream_t)stream, p);
 }
 
 void srt_launch_prepass(const PrepassParams &p, uint64_t max_tris_per_model, void *stream) {

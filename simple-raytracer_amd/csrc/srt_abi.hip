@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -59,6 +60,12 @@ struct srt_tracer {
 	DevBuf<uint32_t> wtri_offset;
 	DevBuf<float> sky;
 	DevBuf<unsigned long long> counters;
+	DevBuf<float> radiance;  // 3 floats per (pixel, sample) of the current batch
+	DevBuf<float> running;   // float4 per pixel, carries the ordered sum across batches
+	size_t radiance_budget = 0; // bytes; 0 = pick from free HBM at first use
+	int num_cus = 0;
+	hipEvent_t ev_k0 = nullptr, ev_k1 = nullptr; // around the trace KERNELS only (reduce excluded)
+	float last_trace_kernel_ms = 0.f, last_reduce_ms = 0.f;
 	int sky_w = 0, sky_h = 0;
 	srt_scene_data sd{};
 	int num_models = 0;
@@ -66,7 +73,7 @@ struct srt_tracer {
 	bool count_tris = false;
 	int rank = 0, world = 1, rows_per_block = 8, owned_rows = 0;
 	hipEvent_t ev_t0 = nullptr, ev_t1 = nullptr, ev_r0 = nullptr, ev_r1 = nullptr;
-	bool have_trace_ev = false, have_resolve_ev = false;
+	bool have_trace_ev = false, have_resolve_ev = false, have_kernel_ev = false;
 	std::string err;
 };
 
@@ -164,6 +171,11 @@ int srt_create(int width, int height, int device_index, srt_tracer **out) {
 	};
 	if ((e = hipSetDevice(device_index)) != hipSuccess) return bail("hipSetDevice", e);
 	if ((e = hipStreamCreateWithFlags(&t->own_stream, hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate", e);
+	{
+		hipDeviceProp_t prop;
+		if ((e = hipGetDeviceProperties(&prop, device_index)) != hipSuccess) return bail("hipGetDeviceProperties", e);
+		t->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+	}
 	t->stream = t->own_stream;
 	const size_t px = (size_t)width * height;
 	if ((e = t->canvas_own.reserve(px * 4)) != hipSuccess) return bail("canvas alloc", e);
@@ -177,7 +189,8 @@ int srt_create(int width, int height, int device_index, srt_tracer **out) {
 	    (e = t->wtris.reserve(SRT_WTRI_FLOATS + 64)) != hipSuccess || (e = t->wtri_offset.reserve(1)) != hipSuccess)
 		return bail("scene alloc", e);
 	if ((e = hipEventCreate(&t->ev_t0)) != hipSuccess || (e = hipEventCreate(&t->ev_t1)) != hipSuccess ||
-	    (e = hipEventCreate(&t->ev_r0)) != hipSuccess || (e = hipEventCreate(&t->ev_r1)) != hipSuccess)
+	    (e = hipEventCreate(&t->ev_r0)) != hipSuccess || (e = hipEventCreate(&t->ev_r1)) != hipSuccess ||
+	    (e = hipEventCreate(&t->ev_k0)) != hipSuccess || (e = hipEventCreate(&t->ev_k1)) != hipSuccess)
 		return bail("hipEventCreate", e);
 	if ((e = hipMemsetAsync(t->canvas, 0, t->canvas_bytes, t->stream)) != hipSuccess) return bail("canvas clear", e);
 	if ((e = hipMemsetAsync(t->counters.ptr, 0, SRT_CTR_COUNT * sizeof(unsigned long long), t->stream)) != hipSuccess)
@@ -203,10 +216,14 @@ void srt_destroy(srt_tracer *t) {
 	t->wtri_offset.release();
 	t->sky.release();
 	t->counters.release();
+	t->radiance.release();
+	t->running.release();
 	if (t->ev_t0) (void)hipEventDestroy(t->ev_t0);
 	if (t->ev_t1) (void)hipEventDestroy(t->ev_t1);
 	if (t->ev_r0) (void)hipEventDestroy(t->ev_r0);
 	if (t->ev_r1) (void)hipEventDestroy(t->ev_r1);
+	if (t->ev_k0) (void)hipEventDestroy(t->ev_k0);
+	if (t->ev_k1) (void)hipEventDestroy(t->ev_k1);
 	if (t->own_stream) (void)hipStreamDestroy(t->own_stream);
 	delete t;
 }
@@ -407,11 +424,78 @@ int srt_trace(srt_tracer *t, const srt_render_data *options) {
 	p.world = t->world;
 	p.rows_per_block = t->rows_per_block;
 	p.owned_rows = t->owned_rows;
+	// ---- batches of samples: radiance[pixel][sample] must fit the HBM budget ----------
+	const size_t pixels = owned_pixels(t);
+	const int ns = options->num_samples;
+	if (t->radiance_budget == 0) {
+		size_t free_b = 0, total_b = 0;
+		SRT_HIP(t, hipMemGetInfo(&free_b, &total_b));
+		size_t budget = free_b / 2; // leave half of what is free to the caller
+		const size_t cap = (size_t)96 << 30;
+		if (budget > cap) budget = cap;
+		if (const char *env = getenv("SRT_RADIANCE_BUDGET_MB")) {
+			const long long mb = atoll(env);
+			if (mb > 0) budget = (size_t)mb << 20;
+		}
+		t->radiance_budget = budget;
+	}
+	uint32_t batch = ns > 0 ? (uint32_t)ns : 0u;
+	if (pixels > 0 && batch > 0) {
+		size_t fit = t->radiance_budget / (pixels * 12);
+		if (fit < 1) fit = 1;
+		if (fit < batch) batch = (uint32_t)fit;
+		if (batch > 4 && (batch & 3u)) batch &= ~3u; // keep the reduce kernel's 16-byte loads aligned
+	}
+	const uint32_t n_batches = batch ? ((uint32_t)ns + batch - 1) / batch : 0u;
+	if (batch) SRT_HIP(t, t->radiance.reserve(pixels * (size_t)batch * 3 + 4));
+	if (n_batches > 1) SRT_HIP(t, t->running.reserve(pixels * 4));
+	p.radiance = t->radiance.ptr;
+	p.queue = t->counters.ptr + SRT_CTR_QUEUE;
+	const int slots = t->num_cus * 4 * srt_trace_waves_per_simd();
+
+	ReduceParams rp;
+	rp.radiance = t->radiance.ptr;
+	rp.running = t->running.ptr;
+	rp.canvas = t->canvas;
+	rp.counters = t->counters.ptr;
+	rp.num_pixels = (uint32_t)pixels;
+	rp.num_samples = ns;
+
 	SRT_HIP(t, hipEventRecord(t->ev_t0, t->stream));
-	srt_launch_trace(p, t->count_tris, t->stream);
-	SRT_HIP(t, hipGetLastError());
+	if (n_batches == 0) {
+		// num_samples <= 0: no paths; the reduction still applies colour = 0 / num_samples (render.cl:520-522)
+		rp.batch_samples = 0;
+		rp.first_batch = rp.last_batch = 1;
+		srt_launch_reduce(rp, t->stream);
+	}
+	for (uint32_t b = 0; b < n_batches; b++) {
+		const uint32_t s0 = b * batch;
+		const uint32_t nbs = (uint32_t)ns - s0 < batch ? (uint32_t)ns - s0 : batch;
+		p.batch_samples = nbs;
+		p.first_sample = s0;
+		p.total_items = (unsigned long long)pixels * nbs;
+		// jobs: ~8 per resident wave for balance, 64..1024 items, multiple of 64
+		unsigned long long job = p.total_items / ((unsigned long long)slots * 8ull);
+		job = (job / 64ull) * 64ull;
+		if (job < 64ull) job = 64ull;
+		if (job > 1024ull) job = 1024ull;
+		p.job_items = (uint32_t)job;
+		const unsigned long long waves_needed = (p.total_items + 63ull) / 64ull;
+		const int num_waves = (int)(waves_needed < (unsigned long long)slots ? waves_needed : (unsigned long long)slots);
+		SRT_HIP(t, hipMemsetAsync(p.queue, 0, sizeof(unsigned long long), t->stream));
+		if (b == 0) SRT_HIP(t, hipEventRecord(t->ev_k0, t->stream));
+		srt_launch_trace(p, t->count_tris, num_waves, t->stream);
+		SRT_HIP(t, hipGetLastError());
+		if (b == n_batches - 1) SRT_HIP(t, hipEventRecord(t->ev_k1, t->stream));
+		rp.batch_samples = nbs;
+		rp.first_batch = (b == 0);
+		rp.last_batch = (b == n_batches - 1);
+		srt_launch_reduce(rp, t->stream);
+		SRT_HIP(t, hipGetLastError());
+	}
 	SRT_HIP(t, hipEventRecord(t->ev_t1, t->stream));
 	t->have_trace_ev = true;
+	t->have_kernel_ev = n_batches > 0;
 	return SRT_OK;
 }
 
@@ -522,6 +606,22 @@ int srt_last_kernel_ms(srt_tracer *t, float *trace_ms, float *resolve_ms) {
 		*resolve_ms = 0.f;
 		if (t->have_resolve_ev) SRT_HIP(t, hipEventElapsedTime(resolve_ms, t->ev_r0, t->ev_r1));
 	}
+	return SRT_OK;
+}
+
+int srt_set_radiance_budget(srt_tracer *t, size_t bytes) {
+	if (!t) return SRT_ERR_INVALID;
+	t->radiance_budget = bytes; // 0 = choose from free HBM at the next srt_trace
+	return SRT_OK;
+}
+
+int srt_last_trace_kernel_ms(srt_tracer *t, float *kernel_ms) {
+	if (!t) return SRT_ERR_INVALID;
+	if (!kernel_ms) return fail(t, SRT_ERR_INVALID, "srt_last_trace_kernel_ms: NULL");
+	SRT_HIP(t, hipSetDevice(t->device));
+	SRT_HIP(t, hipStreamSynchronize(t->stream));
+	*kernel_ms = 0.f;
+	if (t->have_kernel_ev) SRT_HIP(t, hipEventElapsedTime(kernel_ms, t->ev_k0, t->ev_k1));
 	return SRT_OK;
 }
 

@@ -23,8 +23,8 @@ LIB_PATH = Path(os.environ["SRT_LIB"]) if os.environ.get("SRT_LIB") else PKG / "
 # every symbol include/srt_abi.h declares
 ABI_SYMBOLS = [
     "srt_create", "srt_destroy", "srt_last_error", "srt_set_skybox", "srt_update_scene", "srt_clear_canvas",
-    "srt_render", "srt_trace", "srt_resolve", "srt_resolve_external", "srt_synchronize", "srt_read_canvas", "srt_read_argb",
-    "srt_get_counters", "srt_set_count_triangles", "srt_reset_counters", "srt_last_kernel_ms",
+    "srt_render", "srt_trace", "srt_set_radiance_budget", "srt_resolve", "srt_resolve_external", "srt_synchronize", "srt_read_canvas", "srt_read_argb",
+    "srt_get_counters", "srt_set_count_triangles", "srt_reset_counters", "srt_last_kernel_ms", "srt_last_trace_kernel_ms",
     "srt_device_buffers", "srt_bind_canvas", "srt_bind_stream", "srt_set_partition",
     "srt_partition_owned_rows", "srt_partition_padded_rows", "srt_partition_global_row",
     "srt_partition_unpermute", "srt_selftest_math", "srt_version",
@@ -65,6 +65,8 @@ def load_library():
     lib.srt_render.argtypes = [vp, vp, C.c_uint32, vp]
     lib.srt_trace.argtypes = [vp, vp]
     lib.srt_resolve.argtypes = [vp, C.c_uint32]
+    if hasattr(lib, "srt_set_radiance_budget"):
+        lib.srt_set_radiance_budget.argtypes = [vp, sz]
     lib.srt_synchronize.argtypes = [vp]
     lib.srt_resolve_external.argtypes = [vp, vp, C.c_uint32, C.c_uint32, vp]
     lib.srt_read_canvas.argtypes = [vp, vp]
@@ -73,6 +75,8 @@ def load_library():
     lib.srt_set_count_triangles.argtypes = [vp, i]
     lib.srt_reset_counters.argtypes = [vp]
     lib.srt_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    if hasattr(lib, "srt_last_trace_kernel_ms"):
+        lib.srt_last_trace_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]
     lib.srt_device_buffers.argtypes = [vp, C.POINTER(vp), C.POINTER(sz), C.POINTER(vp), C.POINTER(sz)]
     lib.srt_bind_canvas.argtypes = [vp, vp, sz]
     lib.srt_bind_stream.argtypes = [vp, vp]
@@ -157,6 +161,9 @@ class Tracer:
         rd = R.as_records(self.options, R.RENDER_DATA)
         self._check(self.lib.srt_trace(self._h, _ptr(rd)))
 
+    def set_radiance_budget(self, nbytes):
+        self._check(self.lib.srt_set_radiance_budget(self._h, nbytes))
+
     def resolve(self, ticks_stopped):
         self._check(self.lib.srt_resolve(self._h, ticks_stopped))
 
@@ -196,6 +203,11 @@ class Tracer:
         a, b = C.c_float(), C.c_float()
         self._check(self.lib.srt_last_kernel_ms(self._h, C.byref(a), C.byref(b)))
         return a.value, b.value
+
+    def last_trace_kernel_ms(self):
+        a = C.c_float()
+        self._check(self.lib.srt_last_trace_kernel_ms(self._h, C.byref(a)))
+        return a.value
 
     def device_buffers(self):
         cp, cb, ap, ab = C.c_void_p(), C.c_size_t(), C.c_void_p(), C.c_size_t()

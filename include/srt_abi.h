@@ -40,6 +40,7 @@ typedef struct srt_counters {
 	uint64_t tri_tests;  /* triangle tests executed (render.cl:331) */
 	uint64_t tri_pass_u; /* triangle tests that passed the u-range check (render.cl:260) */
 	uint64_t nan_pixels; /* pixels whose colour of a dispatch was NaN */
+	uint64_t watchdog;   /* waves that left the work loop through its spin bound; must be 0 */
 } srt_counters;
 
 /* ---- life cycle ------------------------------------------------------------- */

@@ -31,11 +31,12 @@ for name in names:
     for i in range(reps + 1):
         t.clear_canvas(); t.reset_counters(); t.trace(); t.synchronize()
         ms.append(t.last_kernel_ms()[0])
+        kms = t.last_trace_kernel_ms()
     c = t.counters()
     if (shapes["type"] == 2).any():
         t.count_triangles(True); t.clear_canvas(); t.reset_counters(); t.trace(); t.synchronize()
         c2 = t.counters(); c["tri_tests"], c["tri_pass_u"] = c2["tri_tests"], c2["tri_pass_u"]
-    out[name] = {"tri_tests": c["tri_tests"], "tri_pass_u": c["tri_pass_u"], "gtri_per_s": round(c["tri_tests"] / max(np.min(ms[1:]), 1e-9) / 1e6, 2),"ms": round(float(np.min(ms[1:])), 3), "med": round(float(np.median(ms[1:])), 3), "mray_s": round(c["rays"] / np.min(ms[1:]) / 1e3, 1),
+    out[name] = {"trace_kernel_only_ms": round(kms, 3), "tri_tests": c["tri_tests"], "tri_pass_u": c["tri_pass_u"], "gtri_per_s": round(c["tri_tests"] / max(np.min(ms[1:]), 1e-9) / 1e6, 2),"ms": round(float(np.min(ms[1:])), 3), "med": round(float(np.median(ms[1:])), 3), "mray_s": round(c["rays"] / np.min(ms[1:]) / 1e3, 1),
                  "checksum": float(np.nansum(t.read_canvas().astype(np.float64)))}
     t.close()
 print(json.dumps(out))

@@ -55,7 +55,7 @@ static_assert(sizeof(WinnerRec) == 32, "WinnerRec 32 B");
  * bit-identical to what the reference recomputes per ray (render.cl:325-328,247-248). */
 #define SRT_WTRI_FLOATS 9
 
-enum { SRT_CTR_RAYS = 0, SRT_CTR_SKY, SRT_CTR_TRI, SRT_CTR_TRI_PASS_U, SRT_CTR_NAN, SRT_CTR_PATHS, SRT_CTR_QUEUE, SRT_CTR_COUNT };
+enum { SRT_CTR_RAYS = 0, SRT_CTR_SKY, SRT_CTR_TRI, SRT_CTR_TRI_PASS_U, SRT_CTR_NAN, SRT_CTR_PATHS, SRT_CTR_QUEUE, SRT_CTR_WATCHDOG, SRT_CTR_COUNT };
 
 struct TraceParams {
 	srt_render_data rd;
@@ -80,8 +80,8 @@ struct TraceParams {
 	unsigned long long total_items;  /* owned pixels * batch_samples */
 	uint32_t batch_samples;          /* samples per pixel in this batch */
 	uint32_t first_sample;           /* sample index of the batch's first sample */
-	uint32_t job_items;              /* items a wave reserves per atomic */
-	uint32_t _pad1;
+	uint32_t job_items;              /* items a wave reserves per atomic (multiple of the LDS sub-job size) */
+	uint32_t stage_off;              /* float offset of the radiance staging buffers inside dynamic LDS */
 	int32_t sky_w, sky_h;
 	int32_t num_models;
 	int32_t rank, world, rows_per_block, owned_rows;
@@ -119,7 +119,8 @@ struct ResolveParams {
 
 void srt_launch_trace(TraceParams p, bool count_triangles, int num_waves, void *stream);
 void srt_launch_reduce(const ReduceParams &p, void *stream);
-int srt_trace_waves_per_simd(void);
+int srt_trace_waves_per_simd(int has_models);
+int srt_radiance_stride(void); /* floats per work-item in the radiance buffer */
 void srt_launch_prepass(const PrepassParams &p, uint64_t total_wtris, void *stream);
 void srt_launch_resolve(const ResolveParams &p, void *stream);
 void srt_launch_selftest(unsigned long long *out8, uint32_t stride, void *stream);

@@ -322,15 +322,49 @@ __device__ __forceinline__ f3 sky_box(const TraceParams &p, f3 dir) {
 // ---------------------------------------------------------------------------------
 // Trace kernel. 64-thread workgroups = one wave = one 8x8 pixel tile.
 // ---------------------------------------------------------------------------------
+#ifndef SRT_SUB
+#define SRT_SUB 256 // items per LDS-staged sub-job: 3072 B = 48 whole 64-byte lines per flush
+#endif
+#ifndef SRT_STAGE
+#define SRT_STAGE 1 // 1: radiance staged in LDS and flushed per sub-job; 0: each lane stores its own item
+#endif
+#ifndef SRT_RAD_STRIDE
+#define SRT_RAD_STRIDE 3 // floats per work-item in the radiance buffer (3 = packed rgb, 4 = 16-byte aligned)
+#endif
+
+namespace {
+// One wave copies n floats (n = 3 * items) from its LDS staging buffer to HBM, 16 B per
+// lane per store; dst is 16-byte aligned (sub-jobs start on multiples of SRT_SUB items).
+__device__ __forceinline__ void flush_stage(const float *__restrict__ src, float *__restrict__ dst, uint32_t n, int lane) {
+	// One-wave workgroup: the LDS executes this wave's ds_write / ds_read in program order, so no
+	// s_barrier is needed, and a __syncthreads() here would also wait (vmcnt(0)) for the previous
+	// flush's global stores to drain, exposing the full store latency once per sub-job. Only keep
+	// the compiler from reordering across this point and let the LDS writes land.
+	asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+	const uint32_t n4 = n >> 2;
+	const float4 *__restrict__ s4 = reinterpret_cast<const float4 *>(src);
+	float4 *__restrict__ d4 = reinterpret_cast<float4 *>(dst);
+	for (uint32_t i = (uint32_t)lane; i < n4; i += 64u) d4[i] = s4[i];
+	for (uint32_t i = (n4 << 2) + (uint32_t)lane; i < n; i += 64u) dst[i] = src[i];
+	asm volatile("" ::: "memory"); // later ds_writes into this buffer stay behind the reads above
+}
+} // namespace
+
+// Waves per SIMD the register allocator is asked for (A/B on MI355X, profiles/): the
+// sphere/plane kernel is fastest at 5 (96 VGPRs), the mesh kernels at 4 (128 VGPRs: the
+// triangle loop spills at 96).
 #ifndef SRT_TRACE_WAVES_PER_SIMD
-#define SRT_TRACE_WAVES_PER_SIMD 5 // register budget: 96 VGPRs per lane; +4 % over 4 waves (A/B, profiles/)
+#define SRT_TRACE_WAVES_PER_SIMD 5
+#endif
+#ifndef SRT_TRACE_WAVES_PER_SIMD_MODELS
+#define SRT_TRACE_WAVES_PER_SIMD_MODELS 4
 #endif
 
 // HAS_MODELS = false compiles every AABB / triangle / mesh-normal path out: scenes of
 // spheres and planes (BASELINE configs 0, 1, 3) get a leaner kernel (fewer registers, no
 // spills, smaller code); the host picks the instantiation from the scene.
 template <bool COUNT_TRIS, bool USE_LDS, bool HAS_MODELS>
-__global__ __launch_bounds__(64, SRT_TRACE_WAVES_PER_SIMD) void srt_trace_kernel(const TraceParams p) {
+__global__ __launch_bounds__(64, HAS_MODELS ? SRT_TRACE_WAVES_PER_SIMD_MODELS : SRT_TRACE_WAVES_PER_SIMD) void srt_trace_kernel(const TraceParams p) {
 	extern __shared__ float4 lds[]; // [2*n_shapes] winner records, then [4*n_materials] materials
 	const int width = p.rd.width;
 	const int lane = threadIdx.x;
@@ -359,44 +393,93 @@ __global__ __launch_bounds__(64, SRT_TRACE_WAVES_PER_SIMD) void srt_trace_kernel
 	// srt_reduce_kernel adds it up per pixel in sample order.
 	const unsigned long long total_items = p.total_items;
 	const uint32_t nbs = p.batch_samples;
-	unsigned long long job_cur = 0, job_end = 0, job_base = 0, job_q0 = 0; // wave-uniform
-	uint32_t job_k0 = 0;                                                   // job_base = job_q0 * nbs + job_k0
+	// Global cursor -> chunk of p.job_items items per atomic -> sub-jobs of SRT_SUB items.
+	// A sub-job's radiances are staged in LDS (two buffers, ping-pong) and written to HBM in
+	// one fully coalesced burst of whole 64-byte lines when its last path has finished,
+	// instead of 12 scattered bytes per lane (which made the L2 fetch every line first).
+	unsigned long long chunk_cur = 0, chunk_end = 0;                 // wave-uniform
+	unsigned long long base0 = 0, base1 = 0, sub_q0 = 0;             // first item of the sub-job in buffer 0 / 1
+	uint32_t total0 = 0, total1 = 0;                                 // items of the sub-job staged in each buffer (0 = free)
+	uint32_t issued = 0, sub_k0 = 0, cur = 0;                        // issue cursor of the current buffer `cur`
 	bool queue_dry = (total_items == 0);
+	float *__restrict__ stage = reinterpret_cast<float *>(lds) + p.stage_off; // [2][SRT_SUB][3]
 
 	f3 org = mk(0.f, 0.f, 0.f), dir = mk(0.f, 0.f, 0.f), mask = mk(1.f, 1.f, 1.f), color = mk(0.f, 0.f, 0.f);
 	uint32_t seed = 0;
-	unsigned long long item = 0;
+	uint32_t slot = 0; // lane's item = base[bi] + slot
+	uint32_t bi = 0;
+	unsigned long long item = 0; // only live when !SRT_STAGE
 	int bounce = 0;
 	bool active = false;
-	uint32_t n_rays = 0, n_sky = 0, n_tri = 0, n_tri_u = 0, n_paths = 0;
+	// rays / sky / paths are counted per WAVE with popcounts of the exec mask (scalar adds, no
+	// VGPRs); only the instrumented triangle counters stay per lane.
+	unsigned long long w_rays = 0, w_sky = 0, w_paths = 0;
+	uint32_t n_tri = 0, n_tri_u = 0;
+	uint32_t idle_spins = 0;
 
 	for (;;) {
 		// ---- refill idle lanes -----------------------------------------------------------
 		const unsigned long long want = __ballot(!active);
 		if (want != 0ull && !queue_dry) {
-			if (job_cur == job_end) {
-				unsigned long long start = 0;
-				if (lane == 0) start = atomicAdd(p.queue, (unsigned long long)p.job_items);
-				start = (unsigned long long)__shfl((long long)start, 0);
-				if (start >= total_items) {
-					queue_dry = true;
-				} else {
-					job_cur = job_base = start;
-					job_end = start + p.job_items < total_items ? start + p.job_items : total_items;
-					job_q0 = start / nbs; // the only 64-bit division, once per job
-					job_k0 = (uint32_t)(start - job_q0 * nbs);
+			const uint32_t cur_total0 = cur ? total1 : total0;
+			if (cur_total0 == 0u || issued == cur_total0) {
+				// current sub-job fully handed out (or already flushed / none yet): open the next one in
+				// the other buffer, if that is free
+				const uint32_t other = cur ^ 1u;
+				bool other_free = true;
+#if SRT_STAGE
+				if ((other ? total1 : total0) != 0u) {
+					// The other buffer still holds the previous sub-job. It is complete exactly when no
+					// lane is still tracing one of its items: then write it out as whole 64-byte lines.
+					if (__ballot(active && bi == other) != 0ull) {
+						other_free = false; // idle lanes wait an iteration; paths end within num_bounces iterations
+					} else if (other) {
+						flush_stage(stage + SRT_SUB * 3, p.radiance + base1 * 3ull, total1 * 3u, lane);
+						total1 = 0u;
+					} else {
+						flush_stage(stage, p.radiance + base0 * 3ull, total0 * 3u, lane);
+						total0 = 0u;
+					}
+				}
+#endif
+				if (other_free) {
+					if (chunk_cur == chunk_end) {
+						unsigned long long start = 0;
+						if (lane == 0) start = atomicAdd(p.queue, (unsigned long long)p.job_items);
+						start = (unsigned long long)__shfl((long long)start, 0);
+						if (start >= total_items) {
+							queue_dry = true;
+						} else {
+							chunk_cur = start;
+							chunk_end = start + p.job_items < total_items ? start + p.job_items : total_items;
+						}
+					}
+					if (!queue_dry) {
+						const unsigned long long left = chunk_end - chunk_cur;
+						const uint32_t n = left < (unsigned long long)SRT_SUB ? (uint32_t)left : (uint32_t)SRT_SUB;
+						if (other) base1 = chunk_cur, total1 = n;
+						else base0 = chunk_cur, total0 = n;
+						sub_q0 = chunk_cur / nbs; // one 64-bit division per sub-job
+						sub_k0 = (uint32_t)(chunk_cur - sub_q0 * nbs);
+						chunk_cur += n;
+						cur = other;
+						issued = 0;
+					}
 				}
 			}
-			if (!queue_dry) {
-				const unsigned long long avail = job_end - job_cur;
+			const uint32_t cur_total = cur ? total1 : total0;
+			if (issued < cur_total) {
+				const uint32_t avail = cur_total - issued;
 				const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(want >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)want, 0u));
 				const uint32_t nwant = (uint32_t)__popcll(want);
 				if (!active && rank < avail) {
 					// ---- new camera path (render.cl:488,496-516) ----
-					item = job_cur + rank;
-					const uint32_t off = job_k0 + (uint32_t)(item - job_base); // < nbs + job_items: 32-bit math from here
+					slot = issued + rank;
+					bi = cur;
+					item = (cur ? base1 : base0) + slot;
+					const uint32_t off = sub_k0 + slot; // < nbs + SRT_SUB: 32-bit math from here
 					const uint32_t dq = off / nbs;
-					const unsigned long long q = job_q0 + dq;
+					const unsigned long long q = sub_q0 + dq;
 					const uint32_t sample = p.first_sample + (off - dq * nbs);
 					const uint32_t lrow = (uint32_t)(q / (uint32_t)width);
 					const int px = (int)(q - (unsigned long long)lrow * (uint32_t)width);
@@ -413,21 +496,30 @@ __global__ __launch_bounds__(64, SRT_TRACE_WAVES_PER_SIMD) void srt_trace_kernel
 					color = mk(0.f, 0.f, 0.f);
 					bounce = 0;
 					active = true;
-					n_paths++;
 				}
-				job_cur += nwant < avail ? nwant : avail;
+				const uint32_t handed = nwant < avail ? nwant : avail;
+				issued += handed;
+				w_paths += handed;
 			}
 		}
 		if (!__any(active)) {
 			if (queue_dry) break;
-			continue; // the job ran out mid-refill: fetch the next one
+			// the sub-job ran out mid-refill: open the next one. Bounded: a wave that spins here
+			// without ever getting work leaves with the watchdog counter set instead of hanging.
+			if (++idle_spins > (1u << 20)) {
+				if (lane == 0) atomicAdd(&p.counters[SRT_CTR_WATCHDOG], 1ull);
+				break;
+			}
+			continue;
 		}
+		idle_spins = 0;
 
+		if (nb > 0) w_rays += (unsigned long long)__popcll(__ballot(active));
+		bool fin = false, missed = false;
 		if (active) {
 			bool done = (nb <= 0); // render.cl:403: no bounce loop at all -> colour 0
 			if (!done) {
 			// ---- closest_intersection (render.cl:293-378), winner deferred ----
-			n_rays++;
 			float tmin = DM_INF_F;
 			int best = -1;
 			uint32_t best_tri = 0;
@@ -581,7 +673,7 @@ __global__ __launch_bounds__(64, SRT_TRACE_WAVES_PER_SIMD) void srt_trace_kernel
 				}
 			} else {
 				// miss: sky (render.cl:463-467)
-				n_sky++;
+				missed = true;
 				mask = mask * sky_box(p, dir);
 				color = color + mask;
 				done = true;
@@ -589,23 +681,37 @@ __global__ __launch_bounds__(64, SRT_TRACE_WAVES_PER_SIMD) void srt_trace_kernel
 
 			} // !done
 			if (done) {
+#if SRT_STAGE
+				float *__restrict__ out = stage + (bi * (uint32_t)SRT_SUB + slot) * 3u;
+				out[0] = color.x;
+				out[1] = color.y;
+				out[2] = color.z;
+#elif SRT_RAD_STRIDE == 4
+				*reinterpret_cast<float4 *>(p.radiance + item * 4ull) = make_float4(color.x, color.y, color.z, 0.f);
+#else
 				float *__restrict__ out = p.radiance + item * 3ull;
 				out[0] = color.x;
 				out[1] = color.y;
 				out[2] = color.z;
+#endif
 				active = false;
+				fin = true;
 			}
 		}
+
+		(void)fin;
+		w_sky += (unsigned long long)__popcll(__ballot(missed)); // wave-uniform control flow here
 	}
+#if SRT_STAGE
+	// queue dry and no lane active: whatever is still staged is complete
+	if (total0 != 0u) flush_stage(stage, p.radiance + base0 * 3ull, total0 * 3u, lane);
+	if (total1 != 0u) flush_stage(stage + SRT_SUB * 3, p.radiance + base1 * 3ull, total1 * 3u, lane);
+#endif
 
 	// one atomic per wave and counter
-	unsigned long long r = n_rays, k = n_sky, t3 = n_tri, t4 = n_tri_u;
-	unsigned long long np = n_paths;
-	for (int off = 32; off > 0; off >>= 1) {
-		r += __shfl_down(r, off);
-		k += __shfl_down(k, off);
-		np += __shfl_down(np, off);
-		if (COUNT_TRIS) {
+	unsigned long long r = w_rays, k = w_sky, np = w_paths, t3 = n_tri, t4 = n_tri_u;
+	if (COUNT_TRIS) {
+		for (int off = 32; off > 0; off >>= 1) {
 			t3 += __shfl_down(t3, off);
 			t4 += __shfl_down(t4, off);
 		}
@@ -636,9 +742,15 @@ __global__ __launch_bounds__(256) void srt_reduce_kernel(const ReduceParams p) {
 		c = mk(v.x, v.y, v.z);
 	}
 	const uint32_t n = p.batch_samples;
-	const float *__restrict__ r = p.radiance + (size_t)q * n * 3u;
+	const float *__restrict__ r = p.radiance + (size_t)q * n * (size_t)SRT_RAD_STRIDE;
 	uint32_t k = 0;
-	if ((n & 3u) == 0u) {
+#if SRT_RAD_STRIDE == 4
+	for (; k < n; k++) {
+		const float4 a = reinterpret_cast<const float4 *>(r)[k];
+		c = c + mk(a.x, a.y, a.z);
+	}
+#endif
+	if (SRT_RAD_STRIDE == 3 && (n & 3u) == 0u) {
 		// 4 samples = 48 B = three aligned 16-byte loads; additions stay in sample order
 		const float4 *__restrict__ r4 = reinterpret_cast<const float4 *>(r);
 		for (; k < n; k += 4) {
@@ -649,7 +761,7 @@ __global__ __launch_bounds__(256) void srt_reduce_kernel(const ReduceParams p) {
 			c = c + mk(b.z, b.w, d.x);
 			c = c + mk(d.y, d.z, d.w);
 		}
-	} else {
+	} else if (SRT_RAD_STRIDE == 3) {
 		for (; k < n; k++) c = c + mk(r[3 * k], r[3 * k + 1], r[3 * k + 2]);
 	}
 	if (p.last_batch) {
@@ -769,27 +881,32 @@ void srt_launch_selftest(unsigned long long *out, uint32_t stride, void *stream)
 // ---------------------------------------------------------------------------------
 // launch wrappers (host)
 // ---------------------------------------------------------------------------------
-int srt_trace_waves_per_simd(void) { return SRT_TRACE_WAVES_PER_SIMD; }
+int srt_trace_waves_per_simd(int has_models) { return has_models ? SRT_TRACE_WAVES_PER_SIMD_MODELS : SRT_TRACE_WAVES_PER_SIMD; }
+int srt_radiance_stride(void) { return SRT_RAD_STRIDE; }
 
 void srt_launch_trace(TraceParams p, bool count_triangles, int num_waves, void *stream) {
 	if (p.total_items == 0 || num_waves <= 0) return;
 	dim3 grid((unsigned)num_waves), block(64);
 	// winners + materials go to LDS when small enough not to cost occupancy (20 waves/CU x 8 KB = 160 KB)
-	const size_t need = (size_t)p.sd.num_shapes * sizeof(WinnerRec) + (size_t)p.num_materials * sizeof(srt_material);
-	const bool use_lds = need <= 8192;
-	p.lds_bytes = use_lds ? (uint32_t)need : 0u;
+	// winners + materials go to LDS when small enough not to cost occupancy (20 waves/CU x (3 + 4.5) KB < 160 KB)
+	const size_t scene = (size_t)p.sd.num_shapes * sizeof(WinnerRec) + (size_t)p.num_materials * sizeof(srt_material);
+	const bool use_lds = scene <= 4608;
+	const size_t scene_lds = use_lds ? scene : 0; // both record types are multiples of 16 B
+	p.lds_bytes = (uint32_t)scene_lds;
+	p.stage_off = (uint32_t)(scene_lds / sizeof(float));
+	const size_t need = scene_lds + 2u * SRT_SUB * 3u * sizeof(float);
 	hipStream_t st = (hipStream_t)stream;
 	const bool models = p.num_models > 0;
-	auto go = [&](auto kernel, size_t lds) { hipLaunchKernelGGL(kernel, grid, block, lds, st, p); };
+	auto go = [&](auto kernel) { hipLaunchKernelGGL(kernel, grid, block, need, st, p); };
 	if (!models) {
-		if (use_lds) go(srt_trace_kernel<false, true, false>, need);
-		else go(srt_trace_kernel<false, false, false>, 0);
+		if (use_lds) go(srt_trace_kernel<false, true, false>);
+		else go(srt_trace_kernel<false, false, false>);
 	} else if (use_lds) {
-		if (count_triangles) go(srt_trace_kernel<true, true, true>, need);
-		else go(srt_trace_kernel<false, true, true>, need);
+		if (count_triangles) go(srt_trace_kernel<true, true, true>);
+		else go(srt_trace_kernel<false, true, true>);
 	} else {
-		if (count_triangles) go(srt_trace_kernel<true, false, true>, 0);
-		else go(srt_trace_kernel<false, false, true>, 0);
+		if (count_triangles) go(srt_trace_kernel<true, false, true>);
+		else go(srt_trace_kernel<false, false, true>);
 	}
 }
 

@@ -32,7 +32,7 @@ ABI_SYMBOLS = [
 
 
 class Counters(C.Structure):
-    _fields_ = [(n, C.c_uint64) for n in ("paths", "rays", "sky", "tri_tests", "tri_pass_u", "nan_pixels")]
+    _fields_ = [(n, C.c_uint64) for n in ("paths", "rays", "sky", "tri_tests", "tri_pass_u", "nan_pixels", "watchdog")]
 
     def as_dict(self):
         return {n: int(getattr(self, n)) for n, _ in self._fields_}

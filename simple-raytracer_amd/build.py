@@ -5,6 +5,8 @@ arithmetic (DESIGN.md "Numerics"). hipcc's defaults -fhip-fp32-correctly-rounded
 divide-sqrt and f32 denormal support stay ON (never pass -ffast-math,
 -fgpu-flush-denormals-to-zero or -fno-hip-fp32-correctly-rounded-divide-sqrt here).
 """
+import contextlib
+import fcntl
 import os
 import shutil
 import subprocess
@@ -32,6 +34,19 @@ def stale():
     return any(d.stat().st_mtime > t for d in deps)
 
 
+@contextlib.contextmanager
+def _build_lock():
+    """Serialises builds across processes (torchrun starts one rank per GPU, all of which
+    call build_hip(); only one may run hipcc and write the .so)."""
+    LIBDIR.mkdir(exist_ok=True)
+    with open(LIBDIR / ".build.lock", "w") as f:
+        fcntl.flock(f, fcntl.LOCK_EX)
+        try:
+            yield
+        finally:
+            fcntl.flock(f, fcntl.LOCK_UN)
+
+
 def build_variant(name, extra_flags):
     """A/B experiments: the same sources with extra -D flags -> lib/variants/<name>/libsrt_hip.so."""
     out = LIBDIR / "variants" / name
@@ -49,15 +64,19 @@ def build_hip(force=False, verbose=False, extra_flags=()):
         return Path(os.environ["SRT_LIB"])
     if not force and not stale():
         return LIB
-    LIBDIR.mkdir(exist_ok=True)
-    cmd = [hipcc(), *FLAGS, *extra_flags, "-shared", "-o", str(LIB)] + [str(CSRC / s) for s in SOURCES]
-    if verbose:
-        print(" ".join(cmd))
-    r = subprocess.run(cmd, capture_output=True, text=True)
-    if r.returncode != 0:
-        raise RuntimeError("hipcc failed:\n" + r.stdout + r.stderr)
-    if verbose and r.stderr:
-        print(r.stderr)
+    with _build_lock():
+        if not force and not stale():  # another process built it while we waited
+            return LIB
+        tmp = LIBDIR / f".libsrt_hip.{os.getpid()}.so"
+        cmd = [hipcc(), *FLAGS, *extra_flags, "-shared", "-o", str(tmp)] + [str(CSRC / s) for s in SOURCES]
+        if verbose:
+            print(" ".join(cmd))
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("hipcc failed:\n" + r.stdout + r.stderr)
+        if verbose and r.stderr:
+            print(r.stderr)
+        os.replace(tmp, LIB)  # atomic: a concurrent dlopen sees the old or the new file, never half of one
     return LIB
 
 

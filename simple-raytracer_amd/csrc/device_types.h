@@ -7,23 +7,9 @@
 
 #include "../../include/srt_types.h"
 
-/* Compact per-shape record for the wave-uniform intersection loop. Every lane of a
- * wave tests the SAME shape at the same time (array order, render.cl:299), so these
- * are fetched with scalar loads into SGPRs, not staged per lane.
- *   sphere: f[0..2] centre, f[3] radius*radius (same product as render.cl:187)
- *   plane : f[0..2] position, f[3..5] normal
- *   model : f[0..2] bounding_min, f[3..5] bounding_max, a = first world triangle,
- *           b = triangle count */
-struct LoopShape {
-	int32_t type;
-	uint32_t a;
-	uint32_t b;
-	int32_t _pad;
-	float f[8];
-};
-static_assert(sizeof(LoopShape) == 48, "LoopShape 48 B");
-
-/* v2 layout of the same information. Consecutive shapes of one type form a RUN; the
+/* Scene data for the wave-uniform intersection loop. Every lane of a wave tests the SAME
+ * shape at the same time (array order, render.cl:299), so these records are fetched with
+ * scalar loads into SGPRs, not staged per lane. Consecutive shapes of one type form a RUN; the
  * kernel walks runs in array order (so the first-of-equal-t rule of render.cl:306 is
  * kept) and, inside a run, reads homogeneous packed records with wide scalar loads:
  *   sphere: 4 dwords  {cx, cy, cz, r*r}                    -> 4 spheres per s_load_dwordx16
@@ -60,7 +46,6 @@ enum { SRT_CTR_RAYS = 0, SRT_CTR_SKY, SRT_CTR_TRI, SRT_CTR_TRI_PASS_U, SRT_CTR_N
 struct TraceParams {
 	srt_render_data rd;
 	srt_scene_data sd;
-	const LoopShape *loop_shapes;
 	const ShapeRun *runs;
 	const float *run_data;
 	const WinnerRec *winners;

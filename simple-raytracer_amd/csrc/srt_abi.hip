@@ -404,7 +404,6 @@ int srt_trace(srt_tracer *t, const srt_render_data *options) {
 	} else {
 		memset(&p.sd, 0, sizeof p.sd); // kernel arg 1 never set: behave as the empty scene
 	}
-	p.loop_shapes = nullptr;
 	p.runs = t->runs.ptr;
 	p.run_data = t->run_data.ptr;
 	p.winners = t->winners.ptr;

@@ -242,3 +242,23 @@ def test_zero_and_negative_sample_counts(T, sky, oracle):
         want = oracle.render(rd, g["sd"], g["shapes"], g["tris"], g["mats"], sky)
         assert bits_equal(t.read_canvas(), want)
         t.close()
+
+
+def test_nan_poisoning_is_reproduced_and_counted(T, sky, oracle):
+    """The reference lets a NaN radiance poison a pixel for good (render.cl:522, SURVEY
+    H4). Force it with a NaN material colour: same pixels NaN on GPU and oracle, the
+    nan_pixels counter agrees, and the resolve maps NaN to byte 0 instead of crashing."""
+    g = CASES["spheres"]
+    mats = g["mats"].copy()
+    mats["color"][3] = (np.nan, 0.5, 0.5)  # the big diffuse sphere
+    t = make_tracer(T, dict(g, mats=mats), sky)
+    t.reset_counters()
+    out = t.render(1)
+    got = t.read_canvas()
+    want, oc = oracle.render(g["rd"], g["sd"], g["shapes"], g["tris"], mats, sky, counters=True)
+    assert np.isnan(want[..., 0]).sum() > 100
+    assert bits_equal(got, want)
+    assert t.counters()["nan_pixels"] == oc["nan_pixels"] > 0
+    assert np.array_equal(out.reshape(want.shape[:2] + (4,)), oracle.average(1, want))
+    assert t.counters()["watchdog"] == 0
+    t.close()

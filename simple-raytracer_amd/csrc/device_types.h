@@ -68,6 +68,11 @@ struct TraceParams {
 	uint32_t job_items;              /* items a wave reserves per atomic (multiple of the LDS sub-job size) */
 	uint32_t stage_off;              /* float offset of the radiance staging buffers inside dynamic LDS */
 	int32_t sky_w, sky_h;
+	/* wave-uniform values precomputed on the host so they arrive in SGPRs instead of being
+	 * recomputed (and kept in VGPRs / spilled masks) by every persistent wave */
+	float f_width, f_height, f_sky_w, f_sky_h; /* exact int -> float conversions */
+	int32_t sun_focus_int;                     /* dm_pow_small_int(sd.sun_focus): 1..32, or 0 = general pow */
+	int32_t _pad2;
 	int32_t num_models;
 	int32_t rank, world, rows_per_block, owned_rows;
 };

@@ -284,11 +284,11 @@ __device__ __forceinline__ int global_row(int local_row, int rank, int world, in
 }
 
 // Manual float bilinear, OpenCL 3.0 §8.2 CLAMP_TO_EDGE + LINEAR, normalized coords
-__device__ __forceinline__ f3 sample_sky(const float *__restrict__ sky, int W, int H, float s, float t) {
-	float fu = s * (float)W - 0.5f;
-	float fv = t * (float)H - 0.5f;
-	float cu = dm_clamp(fu, -1.0f, (float)W);
-	float cv = dm_clamp(fv, -1.0f, (float)H);
+__device__ __forceinline__ f3 sample_sky(const float *__restrict__ sky, int W, int H, float fW, float fH, float s, float t) {
+	float fu = s * fW - 0.5f;
+	float fv = t * fH - 0.5f;
+	float cu = dm_clamp(fu, -1.0f, fW);
+	float cv = dm_clamp(fv, -1.0f, fH);
 	if (!(cu == cu)) cu = 0.0f;
 	if (!(cv == cv)) cv = 0.0f;
 	float x0f = __builtin_floorf(cu), y0f = __builtin_floorf(cv);
@@ -310,11 +310,18 @@ __device__ __forceinline__ f3 sample_sky(const float *__restrict__ sky, int W, i
 // render.cl:380-394
 __device__ __forceinline__ f3 sky_box(const TraceParams &p, f3 dir) {
 	f3 sun_dir = ld3(p.sd.sun_direction);
-	float lobe = dm_powf(dm_max(dot3(dir, neg(sun_dir)), 0.0f), p.sd.sun_focus);
+	// dm_powf(x, sun_focus) with its (wave-uniform) choice of path made once on the host
+	const float lobe_x = dm_max(dot3(dir, neg(sun_dir)), 0.0f);
+	float lobe;
+	if (p.sun_focus_int > 0) {
+		lobe = dm_powi(lobe_x, p.sun_focus_int); // dm_powf's x == 1 and NaN cases fall out of the products
+	} else {
+		lobe = dm_powf(lobe_x, p.sd.sun_focus);
+	}
 	f3 sun = (ld3(p.sd.sun_color) * lobe) * p.sd.sun_intensity;
 	float u = dm_atan2pif(dir.z, dir.x) * 0.5f + 0.5f;
 	float v = dir.y * 0.5f + 0.5f;
-	return sample_sky(p.sky, p.sky_w, p.sky_h, u, v) + sun;
+	return sample_sky(p.sky, p.sky_w, p.sky_h, p.f_sky_w, p.f_sky_h, u, v) + sun;
 }
 
 } // namespace
@@ -341,11 +348,17 @@ __device__ __forceinline__ void flush_stage(const float *__restrict__ src, float
 	// flush's global stores to drain, exposing the full store latency once per sub-job. Only keep
 	// the compiler from reordering across this point and let the LDS writes land.
 	asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#ifdef SRT_FLUSH_DWORD
+	// one dword per lane per store: 256 contiguous bytes per wave instruction (4 whole lines), and
+	// only one live VGPR of payload at a point where every lane's path state is live as well
+	for (uint32_t i = (uint32_t)lane; i < n; i += 64u) dst[i] = src[i];
+#else
 	const uint32_t n4 = n >> 2;
 	const float4 *__restrict__ s4 = reinterpret_cast<const float4 *>(src);
 	float4 *__restrict__ d4 = reinterpret_cast<float4 *>(dst);
 	for (uint32_t i = (uint32_t)lane; i < n4; i += 64u) d4[i] = s4[i];
 	for (uint32_t i = (n4 << 2) + (uint32_t)lane; i < n; i += 64u) dst[i] = src[i];
+#endif
 	asm volatile("" ::: "memory"); // later ds_writes into this buffer stay behind the reads above
 }
 } // namespace
@@ -486,8 +499,8 @@ __global__ __launch_bounds__(64, HAS_MODELS ? SRT_TRACE_WAVES_PER_SIMD_MODELS : 
 					const int py = global_row((int)lrow, p.rank, p.world, p.rows_per_block);
 					const uint32_t id = (uint32_t)px + (uint32_t)py * (uint32_t)width;
 					seed = (sample + id * (uint32_t)ns) * p.rd.time * 5304u;
-					float ndc_x = ((float)px + random_float(seed)) / (float)width;
-					float ndc_y = ((float)py + random_float(seed)) / (float)p.rd.height;
+					float ndc_x = ((float)px + random_float(seed)) / p.f_width;
+					float ndc_y = ((float)py + random_float(seed)) / p.f_height;
 					float sx = ((2.f * ndc_x - 1.f) * p.rd.aspect_ratio) * p.rd.fov_scale;
 					float sy = (1.f - 2.f * ndc_y) * p.rd.fov_scale;
 					org = mk(p.rd.camera_to_world[3].x, p.rd.camera_to_world[3].y, p.rd.camera_to_world[3].z);

@@ -11,6 +11,7 @@
 #include <vector>
 
 #include "../../include/srt_abi.h"
+#include "detmath.h"
 #include "device_types.h"
 
 namespace {
@@ -418,6 +419,11 @@ int srt_trace(srt_tracer *t, const srt_render_data *options) {
 	p.counters = t->counters.ptr;
 	p.sky_w = t->sky_w;
 	p.sky_h = t->sky_h;
+	p.f_width = (float)options->width;
+	p.f_height = (float)options->height;
+	p.f_sky_w = (float)t->sky_w;
+	p.f_sky_h = (float)t->sky_h;
+	p.sun_focus_int = dm_pow_small_int(p.sd.sun_focus);
 	p.num_models = t->num_models;
 	p.rank = t->rank;
 	p.world = t->world;

@@ -262,3 +262,36 @@ def test_nan_poisoning_is_reproduced_and_counted(T, sky, oracle):
     assert np.array_equal(out.reshape(want.shape[:2] + (4,)), oracle.average(1, want))
     assert t.counters()["watchdog"] == 0
     t.close()
+
+
+def test_rank_without_rows_and_4k_frame_slice(T, sky, oracle):
+    """(a) More ranks than row blocks: a rank that owns nothing must trace nothing and not
+    fail. (b) BASELINE configs[3] geometry: 8 rows of the 3840x2160 frame (one of 270
+    blocks) against the oracle — exercises 64-bit item / radiance offsets at 4K width."""
+    g = CASES["spheres"]
+    t = T.Tracer(64, 5)
+    t.set_skybox(sky)
+    t.options = R.render_data(64, 5, 2, 4, camera_to_world=S.default_camera())
+    t.scene_data = g["sd"].copy()
+    t.update_scene(g["shapes"], g["tris"], g["mats"])
+    t.set_partition(7, 8, 8)
+    assert t.owned_rows == 0
+    t.reset_counters()
+    t.trace()
+    assert t.read_canvas().shape == (0, 64, 4) and t.counters()["paths"] == 0
+    t.close()
+
+    shapes, tris, mats = S.sphere_scene()
+    rd = R.render_data(3840, 2160, 16, 10, camera_to_world=S.default_camera(), time=4096 + 1)
+    sd = R.scene_data(len(shapes))
+    t = T.Tracer(3840, 2160)
+    t.set_skybox(sky)
+    t.options, t.scene_data = rd, sd
+    t.update_scene(shapes, tris, mats)
+    t.set_partition(200, 270, 8)
+    t.trace()
+    rows = t.read_canvas()
+    want = oracle.render(rd, sd, shapes, tris, mats, sky, rows=(1600, 1608))
+    assert rows.shape[0] == 8 and bits_equal(rows, want[1600:1608])
+    assert t.counters()["watchdog"] == 0
+    t.close()

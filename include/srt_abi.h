@@ -84,6 +84,13 @@ int srt_clear_canvas(srt_tracer *t);
  * With a row partition set (below) only the owned rows are written, packed. */
 int srt_render(srt_tracer *t, const srt_render_data *options, uint32_t ticks_stopped, uint8_t *argb_out);
 
+/* srt_render without the final wait (the front-end's step right after the path,
+ * src/main.cpp:290-337: the host can prepare the next frame while the GPU finishes this
+ * one). Everything is enqueued on the handle's stream, including the copy into argb_out,
+ * which must stay valid — and is only valid to read — after srt_synchronize(). Use
+ * hipHostMalloc'ed memory for a truly asynchronous copy. Frames still execute in order. */
+int srt_render_async(srt_tracer *t, const srt_render_data *options, uint32_t ticks_stopped, uint8_t *argb_out);
+
 /* The two halves of srt_render, asynchronous on the handle's stream, for callers
  * that keep results on the device (bench, multi-GPU gather). */
 int srt_trace(srt_tracer *t, const srt_render_data *options);      /* `render` kernel, render.cl:483 */

@@ -558,6 +558,17 @@ int srt_render(srt_tracer *t, const srt_render_data *options, uint32_t ticks_sto
 	return SRT_OK;
 }
 
+int srt_render_async(srt_tracer *t, const srt_render_data *options, uint32_t ticks_stopped, uint8_t *argb_out) {
+	if (!t) return SRT_ERR_INVALID;
+	if (!argb_out) return fail(t, SRT_ERR_INVALID, "srt_render_async: argb_out is NULL");
+	int rc = srt_trace(t, options);
+	if (rc) return rc;
+	rc = srt_resolve(t, ticks_stopped);
+	if (rc) return rc;
+	SRT_HIP(t, hipMemcpyAsync(argb_out, t->argb.ptr, owned_pixels(t) * 4, hipMemcpyDeviceToHost, t->stream));
+	return SRT_OK; // argb_out is valid after srt_synchronize()
+}
+
 int srt_read_canvas(srt_tracer *t, float *rgba_out) {
 	if (!t) return SRT_ERR_INVALID;
 	if (!rgba_out) return fail(t, SRT_ERR_INVALID, "srt_read_canvas: NULL");

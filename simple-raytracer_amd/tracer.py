@@ -23,7 +23,7 @@ LIB_PATH = Path(os.environ["SRT_LIB"]) if os.environ.get("SRT_LIB") else PKG / "
 # every symbol include/srt_abi.h declares
 ABI_SYMBOLS = [
     "srt_create", "srt_destroy", "srt_last_error", "srt_set_skybox", "srt_update_scene", "srt_clear_canvas",
-    "srt_render", "srt_trace", "srt_set_radiance_budget", "srt_resolve", "srt_resolve_external", "srt_synchronize", "srt_read_canvas", "srt_read_argb",
+    "srt_render", "srt_render_async", "srt_trace", "srt_set_radiance_budget", "srt_resolve", "srt_resolve_external", "srt_synchronize", "srt_read_canvas", "srt_read_argb",
     "srt_get_counters", "srt_set_count_triangles", "srt_reset_counters", "srt_last_kernel_ms", "srt_last_trace_kernel_ms",
     "srt_device_buffers", "srt_bind_canvas", "srt_bind_stream", "srt_set_partition",
     "srt_partition_owned_rows", "srt_partition_padded_rows", "srt_partition_global_row",
@@ -64,6 +64,8 @@ def load_library():
     lib.srt_clear_canvas.argtypes = [vp]
     lib.srt_render.argtypes = [vp, vp, C.c_uint32, vp]
     lib.srt_trace.argtypes = [vp, vp]
+    if hasattr(lib, "srt_render_async"):
+        lib.srt_render_async.argtypes = [vp, vp, C.c_uint32, vp]
     lib.srt_resolve.argtypes = [vp, C.c_uint32]
     if hasattr(lib, "srt_set_radiance_budget"):
         lib.srt_set_radiance_budget.argtypes = [vp, sz]
@@ -157,6 +159,12 @@ class Tracer:
         return output
 
     # -- extras --
+    def render_async(self, ticks_stopped, output):
+        """Enqueue trace + resolve + copy into `output`; valid after synchronize()."""
+        assert output.dtype == np.uint8 and output.size >= self.owned_rows * self.width * 4
+        rd = R.as_records(self.options, R.RENDER_DATA)
+        self._check(self.lib.srt_render_async(self._h, _ptr(rd), ticks_stopped, _ptr(output)))
+
     def trace(self):
         rd = R.as_records(self.options, R.RENDER_DATA)
         self._check(self.lib.srt_trace(self._h, _ptr(rd)))

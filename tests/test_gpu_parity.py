@@ -295,3 +295,21 @@ def test_rank_without_rows_and_4k_frame_slice(T, sky, oracle):
     assert rows.shape[0] == 8 and bits_equal(rows, want[1600:1608])
     assert t.counters()["watchdog"] == 0
     t.close()
+
+
+def test_async_progressive_frames_equal_blocking_frames(T, sky):
+    """The front-end loop (src/main.cpp:277-337) with srt_render_async: enqueue several
+    progressive frames back to back, wait once; last image and canvas equal the blocking
+    sequence of the golden case."""
+    g = CASES["spheres_accum"]
+    t = make_tracer(T, g, sky)
+    h, w = g["argb"].shape[:2]
+    outs = [np.zeros(w * h * 4, np.uint8) for _ in g["frames"]]
+    for i, tm in enumerate(g["frames"]):
+        t.options["time"] = np.uint32(tm)
+        t.render_async(i + 1, outs[i])
+    t.synchronize()
+    assert bits_equal(t.read_canvas(), g["canvas"])
+    assert np.array_equal(outs[-1].reshape(g["argb"].shape), g["argb"])
+    assert not np.array_equal(outs[0], outs[-1])  # earlier frames were really delivered separately
+    t.close()

@@ -491,11 +491,12 @@ __global__ __launch_bounds__(64, HAS_MODELS ? SRT_TRACE_WAVES_PER_SIMD_MODELS : 
 					bi = cur;
 					item = (cur ? base1 : base0) + slot;
 					const uint32_t off = sub_k0 + slot; // < nbs + SRT_SUB: 32-bit math from here
-					const uint32_t dq = off / nbs;
-					const unsigned long long q = sub_q0 + dq;
+					// off / nbs without a division when a sub-job spans at most two pixels (the usual case)
+					const uint32_t dq = (nbs >= (uint32_t)SRT_SUB) ? (off >= nbs ? 1u : 0u) : off / nbs;
+					const uint32_t q = (uint32_t)sub_q0 + dq; // owned pixels < 2^32 (checked by the host)
 					const uint32_t sample = p.first_sample + (off - dq * nbs);
-					const uint32_t lrow = (uint32_t)(q / (uint32_t)width);
-					const int px = (int)(q - (unsigned long long)lrow * (uint32_t)width);
+					const uint32_t lrow = q / (uint32_t)width;
+					const int px = (int)(q - lrow * (uint32_t)width);
 					const int py = global_row((int)lrow, p.rank, p.world, p.rows_per_block);
 					const uint32_t id = (uint32_t)px + (uint32_t)py * (uint32_t)width;
 					seed = (sample + id * (uint32_t)ns) * p.rd.time * 5304u;

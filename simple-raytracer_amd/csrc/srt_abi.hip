@@ -154,6 +154,8 @@ int srt_create(int width, int height, int device_index, srt_tracer **out) {
 	if (!out) return fail(nullptr, SRT_ERR_INVALID, "srt_create: out is NULL");
 	*out = nullptr;
 	if (width <= 0 || height <= 0) return fail(nullptr, SRT_ERR_INVALID, "srt_create: width and height must be positive");
+	if ((uint64_t)width * (uint64_t)height >= (1ull << 31))
+		return fail(nullptr, SRT_ERR_INVALID, "srt_create: width * height must stay below 2^31 pixels (the kernel's pixel id is 32-bit, as in render.cl:488)");
 	int ndev = 0;
 	hipError_t e = hipGetDeviceCount(&ndev);
 	if (e != hipSuccess || ndev <= 0)

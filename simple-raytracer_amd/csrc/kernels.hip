@@ -218,8 +218,8 @@ __device__ __forceinline__ bool test_aabb(float lx, float ly, float lz, float hx
 // it when no lane is left (s_cbranch_execz). Results are therefore bit-identical.
 template <bool COUNT_TRIS>
 __device__ __forceinline__ void test_triangle(float v0x, float v0y, float v0z, float e1x, float e1y, float e1z, float e2x, float e2y,
-                                              float e2z, f3 org, f3 dir, int idx, uint32_t j, float &tmin, int &best, uint32_t &best_tri,
-                                              uint32_t &n_tri_u) {
+                                              float e2z, f3 org, f3 dir, int idx, uint32_t j, uint32_t count, float &tmin, int &best,
+                                              uint32_t &best_tri, uint32_t &n_tri_u) {
 	f3 e1 = mk(e1x, e1y, e1z), e2 = mk(e2x, e2y, e2z);
 	f3 h = cross3(dir, e2);
 	float a = dot3(e1, h);
@@ -231,7 +231,7 @@ __device__ __forceinline__ void test_triangle(float v0x, float v0y, float v0z, f
 		float f = 1.0f / a;
 		float u = f * sh;
 		bool ok = !(u < 0.0f || u > 1.0f);
-		if (COUNT_TRIS) n_tri_u += ok ? 1u : 0u;
+		if (COUNT_TRIS) n_tri_u += (ok && j < count) ? 1u : 0u; // padding triangles (NaN rays reach here) are not tests
 		f3 q = cross3(sv, e1);
 		float v = f * dot3(dir, q);
 		ok = ok && !(v < 0.0f || u + v > 1.0f);
@@ -256,11 +256,12 @@ struct alignas(8) Tri2 {
 };
 
 template <bool COUNT_TRIS>
-__device__ __forceinline__ void test_pair(const Tri2 &t, f3 org, f3 dir, int idx, uint32_t j, float &tmin, int &best, uint32_t &best_tri,
-                                          uint32_t &n_tri_u) {
-	test_triangle<COUNT_TRIS>(t.v[0], t.v[1], t.v[2], t.v[3], t.v[4], t.v[5], t.v[6], t.v[7], t.v[8], org, dir, idx, j, tmin, best, best_tri, n_tri_u);
-	test_triangle<COUNT_TRIS>(t.v[9], t.v[10], t.v[11], t.v[12], t.v[13], t.v[14], t.v[15], t.v[16], t.v[17], org, dir, idx, j + 1u, tmin, best,
-	                          best_tri, n_tri_u);
+__device__ __forceinline__ void test_pair(const Tri2 &t, f3 org, f3 dir, int idx, uint32_t j, uint32_t count, float &tmin, int &best,
+                                          uint32_t &best_tri, uint32_t &n_tri_u) {
+	test_triangle<COUNT_TRIS>(t.v[0], t.v[1], t.v[2], t.v[3], t.v[4], t.v[5], t.v[6], t.v[7], t.v[8], org, dir, idx, j, count, tmin, best, best_tri,
+	                          n_tri_u);
+	test_triangle<COUNT_TRIS>(t.v[9], t.v[10], t.v[11], t.v[12], t.v[13], t.v[14], t.v[15], t.v[16], t.v[17], org, dir, idx, j + 1u, count, tmin,
+	                          best, best_tri, n_tri_u);
 }
 
 template <bool COUNT_TRIS>
@@ -271,9 +272,9 @@ __device__ __forceinline__ void test_triangles(const float *__restrict__ wtris, 
 	Tri2 a = blk[0];
 	for (uint32_t b = 0; b < npair; b += 2) {
 		const Tri2 c = blk[b + 1]; // in flight while `a` is tested
-		test_pair<COUNT_TRIS>(a, org, dir, idx, 2u * b, tmin, best, best_tri, n_tri_u);
+		test_pair<COUNT_TRIS>(a, org, dir, idx, 2u * b, count, tmin, best, best_tri, n_tri_u);
 		a = blk[b + 2];            // in flight while `c` is tested (one pair of slack is allocated past the end)
-		test_pair<COUNT_TRIS>(c, org, dir, idx, 2u * b + 2u, tmin, best, best_tri, n_tri_u);
+		test_pair<COUNT_TRIS>(c, org, dir, idx, 2u * b + 2u, count, tmin, best, best_tri, n_tri_u);
 	}
 }
 

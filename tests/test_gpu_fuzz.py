@@ -1,0 +1,106 @@
+"""GPU: differential fuzzing of the HIP path against the CPU oracle on random — including
+hostile — scenes: degenerate shapes (zero / negative radius, zero or huge normals, flat and
+sliver triangles, empty models, unknown shape types, negative material indices), extreme
+materials (ior 0, NaN / inf / negative parameters), rays starting inside everything,
+cameras with odd matrices. Canvas must stay bit-identical (NaN == NaN), counters equal."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import bits_equal
+from simple_raytracer_amd import records as R, scenes as S
+
+pytestmark = pytest.mark.gpu
+
+
+def random_scene(rng, hostile):
+    n_mats = rng.randint(1, 7)
+    mats = np.zeros(n_mats, R.MATERIAL)
+    for i in range(n_mats):
+        mats[i] = R.material(rng.uniform(0, 1, 3), smoothness=rng.uniform(0, 1), metallic=rng.choice([0, 0, 1, rng.uniform()]),
+                             specular=rng.choice([0, 0, rng.uniform()]), transmittance=rng.choice([0, 0, 1, rng.uniform()]),
+                             refraction_index=rng.choice([1.0, 1.5, 1.33, rng.uniform(0.5, 2.5)]),
+                             emission=rng.uniform(0, 1, 3), emission_strength=rng.choice([0, 0, rng.uniform(0, 5)]))
+    if hostile:
+        m = mats[rng.randint(n_mats)]
+        kind = rng.randint(6)
+        if kind == 0: m["refraction_index"] = 0.0
+        if kind == 1: m["color"] = (np.nan, 1.0, np.inf)
+        if kind == 2: m["smoothness"] = rng.choice([-3.0, 7.0, np.nan])
+        if kind == 3: m["transmittance"], m["refraction_index"] = 1.0, -1.5
+        if kind == 4: m["emission_strength"] = np.inf
+        if kind == 5: m["metallic"] = np.nan
+    box = R.box_triangles()
+    mesh = S.blob_mesh(6, 5, seed=int(rng.randint(100)), smooth=bool(rng.randint(2)))  # 48 triangles
+    extra = np.zeros(6, R.TRIANGLE)
+    for k in range(6):  # hand-made triangles, some degenerate
+        p = rng.uniform(-1, 1, (3, 3)).astype(np.float32)
+        if hostile and k % 3 == 0: p[2] = p[1]                      # zero area
+        if hostile and k % 3 == 1: p[2] = p[0] + (p[1] - p[0]) * 0.5  # collinear
+        extra[k] = R.flat_triangle(rng.normal(size=3), p[0], p[1], p[2])
+    tris = R.concat(R.TRIANGLE, box, mesh, extra)
+    shapes = []
+    for _ in range(rng.randint(1, 10)):
+        mat = int(rng.randint(n_mats))
+        if hostile and rng.rand() < 0.1: mat = -1
+        kind = rng.randint(4)
+        if kind == 0:
+            r = rng.uniform(0.1, 1.5)
+            if hostile and rng.rand() < 0.2: r = rng.choice([0.0, -0.7, 1e-20, 1e20])
+            shapes.append(R.sphere(mat, rng.uniform(-3, 3, 3), r))
+        elif kind == 1:
+            n = rng.normal(size=3) * rng.choice([1.0, 1e-3, 50.0])
+            if hostile and rng.rand() < 0.2: n = np.zeros(3)
+            shapes.append(R.plane(mat, rng.uniform(-3, 3, 3), n))
+        elif kind == 2:
+            first, cnt = [(0, 12), (12, len(mesh)), (12 + len(mesh), 6), (0, 0)][rng.randint(4)]
+            tr = R.mat_mul(R.translate(rng.uniform(-2, 2, 3)), R.mat_mul(R.euler_yxz(*rng.uniform(-3, 3, 2)), R.scale_matrix(rng.uniform(0.2, 1.5, 3))))
+            s = R.model(mat, tris, first, cnt, tr)
+            if hostile and rng.rand() < 0.2:  # bounds that do not match the triangles (the UI's Box::model does that too)
+                s["bounding_min"] -= rng.uniform(0, 2, 3).astype(np.float32)
+                s["bounding_max"] = s["bounding_min"] + rng.uniform(0, 1, 3).astype(np.float32)
+            shapes.append(s)
+        else:
+            s = R.sphere(mat, rng.uniform(-3, 3, 3), 1.0)
+            s["type"] = 7 if hostile else 0  # unknown type: ignored by the kernel (render.cl:301-366)
+            shapes.append(s)
+    arr = np.zeros(len(shapes), R.SHAPE)
+    for i, s in enumerate(shapes):
+        arr[i] = s
+    cam = R.camera_matrix(rng.uniform(-1, 1, 3) + np.array([0, 0.5, 4]), rng.uniform(-0.5, 0.5), rng.uniform(-0.4, 0.4))
+    if hostile and rng.rand() < 0.2:
+        cam[:3, :3] *= np.float32(rng.choice([0.0, 3.0]))  # degenerate / scaled rotation part
+    return arr, tris, mats, cam
+
+
+@pytest.mark.parametrize("hostile", [False, True])
+def test_random_scenes_match_oracle(hostile, sky, oracle):
+    from simple_raytracer_amd import build, tracer as T
+    build.build_hip()
+    rng = np.random.RandomState(20240 + int(hostile))
+    w, h = 24, 16
+    t = T.Tracer(w, h)
+    t.set_skybox(sky)
+    t.count_triangles(True)
+    failures = []
+    for it in range(int(os.environ.get("SRT_FUZZ_ITERS", "40"))):  # soak runs: SRT_FUZZ_ITERS=3000
+        shapes, tris, mats, cam = random_scene(rng, hostile)
+        rd = R.render_data(w, h, int(rng.randint(1, 5)), int(rng.choice([1, 2, 5, 10])), fov_scale=float(rng.uniform(0.3, 2.0)),
+                           camera_to_world=cam, time=int(rng.randint(1, 2**31)), show_normals=bool(rng.rand() < 0.1))
+        sd = R.scene_data(len(shapes), sun_focus=float(rng.choice([25.0, 1.0, 32.0, 7.5, 0.0, 100.0])), sun_intensity=float(rng.uniform(0, 3)))
+        t.options, t.scene_data = rd, sd
+        t.update_scene(shapes, tris, mats)
+        t.clear_canvas()
+        t.reset_counters()
+        t.trace()
+        got = t.read_canvas()
+        c = t.counters()
+        with np.errstate(all="ignore"):
+            want, oc = oracle.render(rd, sd, shapes, tris, mats, sky, counters=True)
+        ok = bits_equal(got, want) and all(c[k] == oc[k] for k in ("paths", "rays", "sky", "tri_tests", "tri_pass_u", "nan_pixels")) and c["watchdog"] == 0
+        if not ok:
+            bad = int((~((got.view(np.uint32) == want.view(np.uint32)) | (np.isnan(got) & np.isnan(want)))).any(axis=-1).sum())
+            failures.append((it, bad, {k: (c[k], oc[k]) for k in ("rays", "sky", "tri_tests", "tri_pass_u", "nan_pixels") if c[k] != oc[k]}))
+    t.close()
+    assert not failures, failures

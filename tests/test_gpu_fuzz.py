@@ -84,7 +84,7 @@ def test_random_scenes_match_oracle(hostile, sky, oracle):
     t.set_skybox(sky)
     t.count_triangles(True)
     failures = []
-    for it in range(int(os.environ.get("SRT_FUZZ_ITERS", "40"))):  # soak runs: SRT_FUZZ_ITERS=3000
+    for it in range(int(os.environ.get("SRT_FUZZ_ITERS", "300"))):  # soak runs: SRT_FUZZ_ITERS=3000
         shapes, tris, mats, cam = random_scene(rng, hostile)
         rd = R.render_data(w, h, int(rng.randint(1, 5)), int(rng.choice([1, 2, 5, 10])), fov_scale=float(rng.uniform(0.3, 2.0)),
                            camera_to_world=cam, time=int(rng.randint(1, 2**31)), show_normals=bool(rng.rand() < 0.1))
@@ -97,7 +97,7 @@ def test_random_scenes_match_oracle(hostile, sky, oracle):
         got = t.read_canvas()
         c = t.counters()
         with np.errstate(all="ignore"):
-            want, oc = oracle.render(rd, sd, shapes, tris, mats, sky, counters=True)
+            want, oc = oracle.render(rd, sd, shapes, tris, mats, sky, counters=True, nthreads=4)
         ok = bits_equal(got, want) and all(c[k] == oc[k] for k in ("paths", "rays", "sky", "tri_tests", "tri_pass_u", "nan_pixels")) and c["watchdog"] == 0
         if not ok:
             bad = int((~((got.view(np.uint32) == want.view(np.uint32)) | (np.isnan(got) & np.isnan(want)))).any(axis=-1).sum())

@@ -66,7 +66,7 @@ struct TraceParams {
 	uint32_t batch_samples;          /* samples per pixel in this batch */
 	uint32_t first_sample;           /* sample index of the batch's first sample */
 	uint32_t job_items;              /* items a wave reserves per atomic (multiple of the LDS sub-job size) */
-	uint32_t stage_off;              /* float offset of the radiance staging buffers inside dynamic LDS */
+	uint32_t stage_off;              /* float4 offset of the staging slots inside dynamic LDS */
 	int32_t sky_w, sky_h;
 	/* wave-uniform values precomputed on the host so they arrive in SGPRs instead of being
 	 * recomputed (and kept in VGPRs / spilled masks) by every persistent wave */
@@ -110,7 +110,7 @@ struct ResolveParams {
 void srt_launch_trace(TraceParams p, bool count_triangles, int num_waves, void *stream);
 void srt_launch_reduce(const ReduceParams &p, void *stream);
 int srt_trace_waves_per_simd(int has_models);
-int srt_radiance_stride(void); /* floats per work-item in the radiance buffer */
+int srt_sub_job_items(int has_models); /* items per LDS-staged sub-job; chunks per atomic are multiples of it */
 void srt_launch_prepass(const PrepassParams &p, uint64_t total_wtris, void *stream);
 void srt_launch_resolve(const ResolveParams &p, void *stream);
 void srt_launch_selftest(unsigned long long *out8, uint32_t stride, void *stream);

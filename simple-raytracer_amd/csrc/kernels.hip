@@ -330,37 +330,45 @@ __device__ __forceinline__ f3 sky_box(const TraceParams &p, f3 dir) {
 // ---------------------------------------------------------------------------------
 // Trace kernel. 64-thread workgroups = one wave = one 8x8 pixel tile.
 // ---------------------------------------------------------------------------------
-#ifndef SRT_SUB
-#define SRT_SUB 256 // items per LDS-staged sub-job: 3072 B = 48 whole 64-byte lines per flush
+// Items per LDS-staged sub-job (two 16-byte-slot buffers per wave). A/B on MI355X: the
+// sphere/plane kernel runs 20 waves per CU, so 2 x 192 x 16 B = 6 KB keeps them all resident
+// (256 would not: -4 %); the mesh kernels run 16 waves per CU and prefer the longer window of
+// 256 (their paths are long: with 192 idle lanes wait more often for the older buffer, -15 %).
+#ifndef SRT_SUB_PLAIN
+#define SRT_SUB_PLAIN 192
 #endif
-#ifndef SRT_STAGE
-#define SRT_STAGE 1 // 1: radiance staged in LDS and flushed per sub-job; 0: each lane stores its own item
-#endif
-#ifndef SRT_RAD_STRIDE
-#define SRT_RAD_STRIDE 3 // floats per work-item in the radiance buffer (3 = packed rgb, 4 = 16-byte aligned)
+#ifndef SRT_SUB_MODELS
+#define SRT_SUB_MODELS 256
 #endif
 
 namespace {
-// One wave copies n floats (n = 3 * items) from its LDS staging buffer to HBM, 16 B per
-// lane per store; dst is 16-byte aligned (sub-jobs start on multiples of SRT_SUB items).
-__device__ __forceinline__ void flush_stage(const float *__restrict__ src, float *__restrict__ dst, uint32_t n, int lane) {
-	// One-wave workgroup: the LDS executes this wave's ds_write / ds_read in program order, so no
-	// s_barrier is needed, and a __syncthreads() here would also wait (vmcnt(0)) for the previous
-	// flush's global stores to drain, exposing the full store latency once per sub-job. Only keep
-	// the compiler from reordering across this point and let the LDS writes land.
+// One wave writes a finished sub-job's radiances (n items, 16-byte slots {r, g, b, -} in
+// LDS) to HBM as packed 12-byte items: whole 64-byte lines, 16 B per lane per store. dst is
+// 16-byte aligned (sub-jobs start on multiples of the sub-job size, a multiple of 4 items).
+//
+// One-wave workgroup: the LDS executes this wave's ds_write / ds_read in program order, so no
+// s_barrier is needed (a __syncthreads() would also wait, vmcnt(0), for the previous flush's
+// global stores to drain). Only keep the compiler from reordering across these points.
+__device__ __forceinline__ void flush_stage(const float *__restrict__ src, float *__restrict__ dst, uint32_t n_items, int lane) {
 	asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#ifdef SRT_FLUSH_DWORD
-	// one dword per lane per store: 256 contiguous bytes per wave instruction (4 whole lines), and
-	// only one live VGPR of payload at a point where every lane's path state is live as well
-	for (uint32_t i = (uint32_t)lane; i < n; i += 64u) dst[i] = src[i];
-#else
-	const uint32_t n4 = n >> 2;
-	const float4 *__restrict__ s4 = reinterpret_cast<const float4 *>(src);
+	const uint32_t n = n_items * 3u, n4 = n >> 2;
 	float4 *__restrict__ d4 = reinterpret_cast<float4 *>(dst);
-	for (uint32_t i = (uint32_t)lane; i < n4; i += 64u) d4[i] = s4[i];
-	for (uint32_t i = (n4 << 2) + (uint32_t)lane; i < n; i += 64u) dst[i] = src[i];
-#endif
-	asm volatile("" ::: "memory"); // later ds_writes into this buffer stay behind the reads above
+	for (uint32_t i = (uint32_t)lane; i < n4; i += 64u) {
+		// packed floats 4i .. 4i+3 live in slots (4i+c)/3, component (4i+c)%3
+		const uint32_t f = 4u * i, it = f / 3u, c = f - 3u * it; // c in {0,1,2}
+		const float *__restrict__ a = src + 4u * it + c;
+		// the four floats never leave slots it and it+1 (+2 when c == 2): walk them explicitly
+		float v0 = a[0];
+		float v1 = (c + 1u < 3u) ? a[1] : a[2];              // c == 2: skip the pad, first float of the next slot
+		float v2 = (c == 0u) ? a[2] : a[3];
+		float v3 = a[4];
+		d4[i] = make_float4(v0, v1, v2, v3);
+	}
+	for (uint32_t f = (n4 << 2) + (uint32_t)lane; f < n; f += 64u) {
+		const uint32_t it = f / 3u;
+		dst[f] = src[4u * it + (f - 3u * it)];
+	}
+	asm volatile("" ::: "memory");
 }
 } // namespace
 
@@ -379,7 +387,8 @@ __device__ __forceinline__ void flush_stage(const float *__restrict__ src, float
 // spills, smaller code); the host picks the instantiation from the scene.
 template <bool COUNT_TRIS, bool USE_LDS, bool HAS_MODELS>
 __global__ __launch_bounds__(64, HAS_MODELS ? SRT_TRACE_WAVES_PER_SIMD_MODELS : SRT_TRACE_WAVES_PER_SIMD) void srt_trace_kernel(const TraceParams p) {
-	extern __shared__ float4 lds[]; // [2*n_shapes] winner records, then [4*n_materials] materials
+	extern __shared__ float4 lds[]; // [2*n_shapes] winner records, [4*n_materials] materials, [2][SRT_SUB] staging slots
+	constexpr uint32_t SRT_SUB = HAS_MODELS ? SRT_SUB_MODELS : SRT_SUB_PLAIN;
 	const int width = p.rd.width;
 	const int lane = threadIdx.x;
 	const int ns = p.rd.num_samples;
@@ -416,13 +425,12 @@ __global__ __launch_bounds__(64, HAS_MODELS ? SRT_TRACE_WAVES_PER_SIMD_MODELS : 
 	uint32_t total0 = 0, total1 = 0;                                 // items of the sub-job staged in each buffer (0 = free)
 	uint32_t issued = 0, sub_k0 = 0, cur = 0;                        // issue cursor of the current buffer `cur`
 	bool queue_dry = (total_items == 0);
-	float *__restrict__ stage = reinterpret_cast<float *>(lds) + p.stage_off; // [2][SRT_SUB][3]
+	float4 *__restrict__ stage = lds + p.stage_off; // [2][SRT_SUB] 16-byte slots: {dir.xyz, seed} before the trace, {r, g, b, -} after
 
 	f3 org = mk(0.f, 0.f, 0.f), dir = mk(0.f, 0.f, 0.f), mask = mk(1.f, 1.f, 1.f), color = mk(0.f, 0.f, 0.f);
 	uint32_t seed = 0;
 	uint32_t slot = 0; // lane's item = base[bi] + slot
 	uint32_t bi = 0;
-	unsigned long long item = 0; // only live when !SRT_STAGE
 	int bounce = 0;
 	bool active = false;
 	// rays / sky / paths are counted per WAVE with popcounts of the exec mask (scalar adds, no
@@ -441,21 +449,19 @@ __global__ __launch_bounds__(64, HAS_MODELS ? SRT_TRACE_WAVES_PER_SIMD_MODELS : 
 				// the other buffer, if that is free
 				const uint32_t other = cur ^ 1u;
 				bool other_free = true;
-#if SRT_STAGE
 				if ((other ? total1 : total0) != 0u) {
 					// The other buffer still holds the previous sub-job. It is complete exactly when no
 					// lane is still tracing one of its items: then write it out as whole 64-byte lines.
 					if (__ballot(active && bi == other) != 0ull) {
 						other_free = false; // idle lanes wait an iteration; paths end within num_bounces iterations
 					} else if (other) {
-						flush_stage(stage + SRT_SUB * 3, p.radiance + base1 * 3ull, total1 * 3u, lane);
+						flush_stage(reinterpret_cast<const float *>(stage + SRT_SUB), p.radiance + base1 * 3ull, total1, lane);
 						total1 = 0u;
 					} else {
-						flush_stage(stage, p.radiance + base0 * 3ull, total0 * 3u, lane);
+						flush_stage(reinterpret_cast<const float *>(stage), p.radiance + base0 * 3ull, total0, lane);
 						total0 = 0u;
 					}
 				}
-#endif
 				if (other_free) {
 					if (chunk_cur == chunk_end) {
 						unsigned long long start = 0;
@@ -473,8 +479,31 @@ __global__ __launch_bounds__(64, HAS_MODELS ? SRT_TRACE_WAVES_PER_SIMD_MODELS : 
 						const uint32_t n = left < (unsigned long long)SRT_SUB ? (uint32_t)left : (uint32_t)SRT_SUB;
 						if (other) base1 = chunk_cur, total1 = n;
 						else base0 = chunk_cur, total0 = n;
-						sub_q0 = chunk_cur / nbs; // one 64-bit division per sub-job
-						sub_k0 = (uint32_t)(chunk_cur - sub_q0 * nbs);
+						// Camera rays of the WHOLE sub-job now, all 64 lanes busy (render.cl:488,496-516), parked
+						// in the staging slots as {dir, seed after the two jitter draws}; a lane that later
+						// takes an item only reads its slot. (One ray set-up per item instead of the set-up
+						// code running, mostly masked off, in every iteration of the segment loop.)
+						const unsigned long long q0 = chunk_cur / nbs; // one 64-bit division per sub-job
+						const uint32_t k0 = (uint32_t)(chunk_cur - q0 * nbs);
+						float4 *__restrict__ slots = stage + other * (uint32_t)SRT_SUB;
+						for (uint32_t sl = (uint32_t)lane; sl < n; sl += 64u) {
+							const uint32_t off = k0 + sl; // < nbs + SRT_SUB: 32-bit math from here
+							const uint32_t dq = (nbs >= (uint32_t)SRT_SUB) ? (off >= nbs ? 1u : 0u) : off / nbs;
+							const uint32_t q = (uint32_t)q0 + dq; // owned pixels < 2^31 (checked by the host)
+							const uint32_t sample = p.first_sample + (off - dq * nbs);
+							const uint32_t lrow = q / (uint32_t)width;
+							const int px = (int)(q - lrow * (uint32_t)width);
+							const int py = global_row((int)lrow, p.rank, p.world, p.rows_per_block);
+							const uint32_t id = (uint32_t)px + (uint32_t)py * (uint32_t)width;
+							uint32_t sd_ = (sample + id * (uint32_t)ns) * p.rd.time * 5304u;
+							float ndc_x = ((float)px + random_float(sd_)) / p.f_width;
+							float ndc_y = ((float)py + random_float(sd_)) / p.f_height;
+							float sx = ((2.f * ndc_x - 1.f) * p.rd.aspect_ratio) * p.rd.fov_scale;
+							float sy = (1.f - 2.f * ndc_y) * p.rd.fov_scale;
+							f3 d0 = normalize3(mat_by_vec(p.rd.camera_to_world, mk(sx, sy, -1.0f), 0.0f));
+							slots[sl] = make_float4(d0.x, d0.y, d0.z, dm_u2f(sd_));
+						}
+						asm volatile("" ::: "memory");
 						chunk_cur += n;
 						cur = other;
 						issued = 0;
@@ -487,26 +516,13 @@ __global__ __launch_bounds__(64, HAS_MODELS ? SRT_TRACE_WAVES_PER_SIMD_MODELS : 
 				const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(want >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)want, 0u));
 				const uint32_t nwant = (uint32_t)__popcll(want);
 				if (!active && rank < avail) {
-					// ---- new camera path (render.cl:488,496-516) ----
+					// ---- next path: its camera ray was prepared when the sub-job was opened ----
 					slot = issued + rank;
 					bi = cur;
-					item = (cur ? base1 : base0) + slot;
-					const uint32_t off = sub_k0 + slot; // < nbs + SRT_SUB: 32-bit math from here
-					// off / nbs without a division when a sub-job spans at most two pixels (the usual case)
-					const uint32_t dq = (nbs >= (uint32_t)SRT_SUB) ? (off >= nbs ? 1u : 0u) : off / nbs;
-					const uint32_t q = (uint32_t)sub_q0 + dq; // owned pixels < 2^32 (checked by the host)
-					const uint32_t sample = p.first_sample + (off - dq * nbs);
-					const uint32_t lrow = q / (uint32_t)width;
-					const int px = (int)(q - lrow * (uint32_t)width);
-					const int py = global_row((int)lrow, p.rank, p.world, p.rows_per_block);
-					const uint32_t id = (uint32_t)px + (uint32_t)py * (uint32_t)width;
-					seed = (sample + id * (uint32_t)ns) * p.rd.time * 5304u;
-					float ndc_x = ((float)px + random_float(seed)) / p.f_width;
-					float ndc_y = ((float)py + random_float(seed)) / p.f_height;
-					float sx = ((2.f * ndc_x - 1.f) * p.rd.aspect_ratio) * p.rd.fov_scale;
-					float sy = (1.f - 2.f * ndc_y) * p.rd.fov_scale;
+					const float4 ray = stage[cur * (uint32_t)SRT_SUB + slot];
+					dir = mk(ray.x, ray.y, ray.z);
+					seed = dm_f2u(ray.w);
 					org = mk(p.rd.camera_to_world[3].x, p.rd.camera_to_world[3].y, p.rd.camera_to_world[3].z);
-					dir = normalize3(mat_by_vec(p.rd.camera_to_world, mk(sx, sy, -1.0f), 0.0f));
 					mask = mk(1.f, 1.f, 1.f);
 					color = mk(0.f, 0.f, 0.f);
 					bounce = 0;
@@ -696,19 +712,7 @@ __global__ __launch_bounds__(64, HAS_MODELS ? SRT_TRACE_WAVES_PER_SIMD_MODELS : 
 
 			} // !done
 			if (done) {
-#if SRT_STAGE
-				float *__restrict__ out = stage + (bi * (uint32_t)SRT_SUB + slot) * 3u;
-				out[0] = color.x;
-				out[1] = color.y;
-				out[2] = color.z;
-#elif SRT_RAD_STRIDE == 4
-				*reinterpret_cast<float4 *>(p.radiance + item * 4ull) = make_float4(color.x, color.y, color.z, 0.f);
-#else
-				float *__restrict__ out = p.radiance + item * 3ull;
-				out[0] = color.x;
-				out[1] = color.y;
-				out[2] = color.z;
-#endif
+				stage[bi * (uint32_t)SRT_SUB + slot] = make_float4(color.x, color.y, color.z, 0.f);
 				active = false;
 				fin = true;
 			}
@@ -717,11 +721,9 @@ __global__ __launch_bounds__(64, HAS_MODELS ? SRT_TRACE_WAVES_PER_SIMD_MODELS : 
 		(void)fin;
 		w_sky += (unsigned long long)__popcll(__ballot(missed)); // wave-uniform control flow here
 	}
-#if SRT_STAGE
 	// queue dry and no lane active: whatever is still staged is complete
-	if (total0 != 0u) flush_stage(stage, p.radiance + base0 * 3ull, total0 * 3u, lane);
-	if (total1 != 0u) flush_stage(stage + SRT_SUB * 3, p.radiance + base1 * 3ull, total1 * 3u, lane);
-#endif
+	if (total0 != 0u) flush_stage(reinterpret_cast<const float *>(stage), p.radiance + base0 * 3ull, total0, lane);
+	if (total1 != 0u) flush_stage(reinterpret_cast<const float *>(stage + SRT_SUB), p.radiance + base1 * 3ull, total1, lane);
 
 	// one atomic per wave and counter
 	unsigned long long r = w_rays, k = w_sky, np = w_paths, t3 = n_tri, t4 = n_tri_u;
@@ -757,15 +759,9 @@ __global__ __launch_bounds__(256) void srt_reduce_kernel(const ReduceParams p) {
 		c = mk(v.x, v.y, v.z);
 	}
 	const uint32_t n = p.batch_samples;
-	const float *__restrict__ r = p.radiance + (size_t)q * n * (size_t)SRT_RAD_STRIDE;
+	const float *__restrict__ r = p.radiance + (size_t)q * n * 3u;
 	uint32_t k = 0;
-#if SRT_RAD_STRIDE == 4
-	for (; k < n; k++) {
-		const float4 a = reinterpret_cast<const float4 *>(r)[k];
-		c = c + mk(a.x, a.y, a.z);
-	}
-#endif
-	if (SRT_RAD_STRIDE == 3 && (n & 3u) == 0u) {
+	if ((n & 3u) == 0u) {
 		// 4 samples = 48 B = three aligned 16-byte loads; additions stay in sample order
 		const float4 *__restrict__ r4 = reinterpret_cast<const float4 *>(r);
 		for (; k < n; k += 4) {
@@ -776,7 +772,7 @@ __global__ __launch_bounds__(256) void srt_reduce_kernel(const ReduceParams p) {
 			c = c + mk(b.z, b.w, d.x);
 			c = c + mk(d.y, d.z, d.w);
 		}
-	} else if (SRT_RAD_STRIDE == 3) {
+	} else {
 		for (; k < n; k++) c = c + mk(r[3 * k], r[3 * k + 1], r[3 * k + 2]);
 	}
 	if (p.last_batch) {
@@ -897,7 +893,7 @@ void srt_launch_selftest(unsigned long long *out, uint32_t stride, void *stream)
 // launch wrappers (host)
 // ---------------------------------------------------------------------------------
 int srt_trace_waves_per_simd(int has_models) { return has_models ? SRT_TRACE_WAVES_PER_SIMD_MODELS : SRT_TRACE_WAVES_PER_SIMD; }
-int srt_radiance_stride(void) { return SRT_RAD_STRIDE; }
+int srt_sub_job_items(int has_models) { return has_models ? SRT_SUB_MODELS : SRT_SUB_PLAIN; }
 
 void srt_launch_trace(TraceParams p, bool count_triangles, int num_waves, void *stream) {
 	if (p.total_items == 0 || num_waves <= 0) return;
@@ -908,8 +904,8 @@ void srt_launch_trace(TraceParams p, bool count_triangles, int num_waves, void *
 	const bool use_lds = scene <= 4608;
 	const size_t scene_lds = use_lds ? scene : 0; // both record types are multiples of 16 B
 	p.lds_bytes = (uint32_t)scene_lds;
-	p.stage_off = (uint32_t)(scene_lds / sizeof(float));
-	const size_t need = scene_lds + 2u * SRT_SUB * 3u * sizeof(float);
+	p.stage_off = (uint32_t)(scene_lds / sizeof(float4));
+	const size_t need = scene_lds + 2u * (size_t)srt_sub_job_items(p.num_models > 0) * sizeof(float4);
 	hipStream_t st = (hipStream_t)stream;
 	const bool models = p.num_models > 0;
 	auto go = [&](auto kernel) { hipLaunchKernelGGL(kernel, grid, block, need, st, p); };

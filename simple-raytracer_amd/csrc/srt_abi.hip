@@ -448,13 +448,13 @@ int srt_trace(srt_tracer *t, const srt_render_data *options) {
 	}
 	uint32_t batch = ns > 0 ? (uint32_t)ns : 0u;
 	if (pixels > 0 && batch > 0) {
-		size_t fit = t->radiance_budget / (pixels * sizeof(float) * (size_t)srt_radiance_stride());
+		size_t fit = t->radiance_budget / (pixels * 12);
 		if (fit < 1) fit = 1;
 		if (fit < batch) batch = (uint32_t)fit;
 		if (batch > 4 && (batch & 3u)) batch &= ~3u; // keep the reduce kernel's 16-byte loads aligned
 	}
 	const uint32_t n_batches = batch ? ((uint32_t)ns + batch - 1) / batch : 0u;
-	if (batch) SRT_HIP(t, t->radiance.reserve(pixels * (size_t)batch * (size_t)srt_radiance_stride() + 4));
+	if (batch) SRT_HIP(t, t->radiance.reserve(pixels * (size_t)batch * 3 + 4));
 	if (n_batches > 1) SRT_HIP(t, t->running.reserve(pixels * 4));
 	p.radiance = t->radiance.ptr;
 	p.queue = t->counters.ptr + SRT_CTR_QUEUE;
@@ -483,9 +483,10 @@ int srt_trace(srt_tracer *t, const srt_render_data *options) {
 		p.total_items = (unsigned long long)pixels * nbs;
 		// chunks per atomic: ~8 per resident wave for balance, 128..1024 items, multiple of the 128-item sub-job
 		unsigned long long job = p.total_items / ((unsigned long long)slots * 8ull);
-		job = (job / 256ull) * 256ull; // multiple of every sub-job size in use (128 or 256)
-		if (job < 256ull) job = 256ull;
-		if (job > 1024ull) job = 1024ull;
+		const unsigned long long sub = (unsigned long long)srt_sub_job_items(t->num_models > 0);
+		job = (job / sub) * sub; // whole sub-jobs, so that every sub-job starts 16-byte aligned in the radiance buffer
+		if (job < sub) job = sub;
+		if (job > 5ull * sub) job = 5ull * sub;
 		p.job_items = (uint32_t)job;
 		const unsigned long long waves_needed = (p.total_items + 63ull) / 64ull;
 		const int num_waves = (int)(waves_needed < (unsigned long long)slots ? waves_needed : (unsigned long long)slots);

@@ -325,17 +325,35 @@ __device__ __forceinline__ f3 sky_box(const TraceParams &p, f3 dir) {
 	return sample_sky(p.sky, p.sky_w, p.sky_h, p.f_sky_w, p.f_sky_h, u, v) + sun;
 }
 
+// Evaluate the sky for the first n queued escapes (n <= 64), one per lane, and finish their
+// paths: mask *= sky; color += mask (render.cl:464-465); the radiance goes to the path's
+// staging slot. Called with all 64 lanes in wave-uniform control flow.
+__device__ __forceinline__ void resolve_ring(const TraceParams &p, const float *__restrict__ ring, uint32_t n, float4 *__restrict__ stage, int lane) {
+	asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // one-wave workgroup: LDS ops are in order; stop compiler motion only
+	if ((uint32_t)lane < n) {
+		const f3 d = mk(ring[0 * 64 + lane], ring[1 * 64 + lane], ring[2 * 64 + lane]);
+		f3 m = mk(ring[3 * 64 + lane], ring[4 * 64 + lane], ring[5 * 64 + lane]);
+		f3 c = mk(ring[6 * 64 + lane], ring[7 * 64 + lane], ring[8 * 64 + lane]);
+		const uint32_t dest = dm_f2u(ring[9 * 64 + lane]);
+		m = m * sky_box(p, d);
+		c = c + m;
+		stage[dest] = make_float4(c.x, c.y, c.z, 0.f);
+	}
+	asm volatile("" ::: "memory");
+}
+
 } // namespace
 
 // ---------------------------------------------------------------------------------
 // Trace kernel. 64-thread workgroups = one wave = one 8x8 pixel tile.
 // ---------------------------------------------------------------------------------
-// Items per LDS-staged sub-job (two 16-byte-slot buffers per wave). A/B on MI355X: the
-// sphere/plane kernel runs 20 waves per CU, so 2 x 192 x 16 B = 6 KB keeps them all resident
-// (256 would not: -4 %); the mesh kernels run 16 waves per CU and prefer the longer window of
-// 256 (their paths are long: with 192 idle lanes wait more often for the older buffer, -15 %).
+// Items per LDS-staged sub-job (two 16-byte-slot buffers per wave, next to the 2.5 KB sky
+// ring). A/B on MI355X: the sphere/plane kernel runs 20 waves per CU and is fastest with
+// 2 x 128 x 16 B = 4 KB (192: -6 %, LDS then limits residency); the mesh kernels run 16 waves
+// per CU and prefer the longer window of 256 (their paths are long: with fewer slots idle
+// lanes wait more often for the older buffer).
 #ifndef SRT_SUB_PLAIN
-#define SRT_SUB_PLAIN 192
+#define SRT_SUB_PLAIN 128
 #endif
 #ifndef SRT_SUB_MODELS
 #define SRT_SUB_MODELS 256
@@ -426,6 +444,8 @@ __global__ __launch_bounds__(64, HAS_MODELS ? SRT_TRACE_WAVES_PER_SIMD_MODELS : 
 	uint32_t issued = 0, sub_k0 = 0, cur = 0;                        // issue cursor of the current buffer `cur`
 	bool queue_dry = (total_items == 0);
 	float4 *__restrict__ stage = lds + p.stage_off; // [2][SRT_SUB] 16-byte slots: {dir.xyz, seed} before the trace, {r, g, b, -} after
+	float *__restrict__ ring = reinterpret_cast<float *>(stage + 2u * SRT_SUB); // [10][64] escaped paths awaiting their sky lookup
+	uint32_t ring_count = 0;                                                    // wave-uniform
 
 	f3 org = mk(0.f, 0.f, 0.f), dir = mk(0.f, 0.f, 0.f), mask = mk(1.f, 1.f, 1.f), color = mk(0.f, 0.f, 0.f);
 	uint32_t seed = 0;
@@ -450,6 +470,10 @@ __global__ __launch_bounds__(64, HAS_MODELS ? SRT_TRACE_WAVES_PER_SIMD_MODELS : 
 				const uint32_t other = cur ^ 1u;
 				bool other_free = true;
 				if ((other ? total1 : total0) != 0u) {
+					if (ring_count != 0u) { // queued escapes may belong to the buffer we are about to judge
+						resolve_ring(p, ring, ring_count, stage, lane);
+						ring_count = 0;
+					}
 					// The other buffer still holds the previous sub-job. It is complete exactly when no
 					// lane is still tracing one of its items: then write it out as whole 64-byte lines.
 					if (__ballot(active && bi == other) != 0ull) {
@@ -703,11 +727,9 @@ __global__ __launch_bounds__(64, HAS_MODELS ? SRT_TRACE_WAVES_PER_SIMD_MODELS : 
 					}
 				}
 			} else {
-				// miss: sky (render.cl:463-467)
+				// miss (render.cl:463-467): the sky is NOT evaluated here, where only ~1 lane in 5 would
+				// be busy; the lane queues {dir, mask, color, slot} in the wave's LDS ring below
 				missed = true;
-				mask = mask * sky_box(p, dir);
-				color = color + mask;
-				done = true;
 			}
 
 			} // !done
@@ -719,9 +741,28 @@ __global__ __launch_bounds__(64, HAS_MODELS ? SRT_TRACE_WAVES_PER_SIMD_MODELS : 
 		}
 
 		(void)fin;
-		w_sky += (unsigned long long)__popcll(__ballot(missed)); // wave-uniform control flow here
+		// ---- deferred sky: queue this iteration's escaped paths (wave-uniform control flow) ----
+		const unsigned long long mm = __ballot(missed);
+		if (mm != 0ull) {
+			const uint32_t n_miss = (uint32_t)__popcll(mm);
+			if (ring_count + n_miss > 64u) {
+				resolve_ring(p, ring, ring_count, stage, lane);
+				ring_count = 0;
+			}
+			if (missed) {
+				const uint32_t e = ring_count + __builtin_amdgcn_mbcnt_hi((uint32_t)(mm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mm, 0u));
+				ring[0 * 64 + e] = dir.x, ring[1 * 64 + e] = dir.y, ring[2 * 64 + e] = dir.z;
+				ring[3 * 64 + e] = mask.x, ring[4 * 64 + e] = mask.y, ring[5 * 64 + e] = mask.z;
+				ring[6 * 64 + e] = color.x, ring[7 * 64 + e] = color.y, ring[8 * 64 + e] = color.z;
+				ring[9 * 64 + e] = dm_u2f(bi * SRT_SUB + slot);
+				active = false; // free for the next item; the radiance reaches the slot when the ring is resolved
+			}
+			ring_count += n_miss;
+			w_sky += n_miss;
+		}
 	}
 	// queue dry and no lane active: whatever is still staged is complete
+	if (ring_count != 0u) resolve_ring(p, ring, ring_count, stage, lane);
 	if (total0 != 0u) flush_stage(reinterpret_cast<const float *>(stage), p.radiance + base0 * 3ull, total0, lane);
 	if (total1 != 0u) flush_stage(reinterpret_cast<const float *>(stage + SRT_SUB), p.radiance + base1 * 3ull, total1, lane);
 
@@ -905,7 +946,7 @@ void srt_launch_trace(TraceParams p, bool count_triangles, int num_waves, void *
 	const size_t scene_lds = use_lds ? scene : 0; // both record types are multiples of 16 B
 	p.lds_bytes = (uint32_t)scene_lds;
 	p.stage_off = (uint32_t)(scene_lds / sizeof(float4));
-	const size_t need = scene_lds + 2u * (size_t)srt_sub_job_items(p.num_models > 0) * sizeof(float4);
+	const size_t need = scene_lds + 2u * (size_t)srt_sub_job_items(p.num_models > 0) * sizeof(float4) + 10u * 64u * sizeof(float);
 	hipStream_t st = (hipStream_t)stream;
 	const bool models = p.num_models > 0;
 	auto go = [&](auto kernel) { hipLaunchKernelGGL(kernel, grid, block, need, st, p); };

@@ -13,6 +13,9 @@
 //    radiance is written to HBM (12 B; 25 GB at 1920x1080x1024 spp, what 288 GB are for)
 //    and srt_reduce_kernel sums them per pixel in sample order, which keeps the canvas
 //    bit-identical to the reference's serial `color += trace(...)` (render.cl:518).
+//  * Phases only a few lanes need at a time are not run masked in every iteration but
+//    batched through LDS at full occupancy: camera-ray set-up for a whole sub-job when it
+//    is opened, and the sky lookup of escaped paths through a 64-entry ring.
 //  * The shape loop index is wave-uniform, so shape records and world-space triangles
 //    arrive through SCALAR loads (s_load_dwordx*) into SGPRs and feed VALU ops as
 //    scalar operands: no per-lane loads, no LDS traffic and no VGPRs for scene data.

@@ -156,9 +156,34 @@ __device__ __forceinline__ float schlick(float r0, float cos_theta) {
 
 
 // ---- wave-uniform scene data: 64-byte blocks fetched with ONE scalar load each ----
-struct alignas(64) Blk16 {
+// The persistent kernel stores to global memory (radiance) inside its main loop, after which
+// the compiler can no longer prove that scene data is not clobbered and would fall back to
+// per-lane VMEM loads of the same address. Reading through the CONSTANT address space states
+// what is true here -- runs, packed records and world triangles are never written by this
+// kernel -- and keeps these loads on the scalar unit (s_load_dwordx*, results in SGPRs).
+#define SRT_AS_CONST __attribute__((address_space(4)))
+struct Blk16 {
 	float v[16];
 };
+struct Tri2 {
+	float v[18];
+};
+template <int N, int ALIGN>
+__device__ __forceinline__ void ld_uniform(const float *p, float (&out)[N]) {
+	const SRT_AS_CONST float *c = (const SRT_AS_CONST float *)__builtin_assume_aligned(p, ALIGN);
+#pragma unroll
+	for (int i = 0; i < N; i++) out[i] = c[i];
+}
+__device__ __forceinline__ Blk16 ld_blk16(const float *p) {
+	Blk16 b;
+	ld_uniform<16, 64>(p, b.v);
+	return b;
+}
+__device__ __forceinline__ Tri2 ld_tri2(const float *p) {
+	Tri2 t;
+	ld_uniform<18, 8>(p, t.v);
+	return t;
+}
 
 __device__ __forceinline__ uint32_t f2u(float f) { return __float_as_uint(f); }
 
@@ -254,9 +279,6 @@ __device__ __forceinline__ void test_triangle(float v0x, float v0y, float v0z, f
 // TWO alternating SGPR sets: the load of the next pair is issued before the current
 // pair is tested, which hides the scalar-cache / L2 latency that a single buffer would
 // expose once per block (the loop is otherwise latency-bound at low occupancy).
-struct alignas(8) Tri2 {
-	float v[18];
-};
 
 template <bool COUNT_TRIS>
 __device__ __forceinline__ void test_pair(const Tri2 &t, f3 org, f3 dir, int idx, uint32_t j, uint32_t count, float &tmin, int &best,
@@ -270,13 +292,13 @@ __device__ __forceinline__ void test_pair(const Tri2 &t, f3 org, f3 dir, int idx
 template <bool COUNT_TRIS>
 __device__ __forceinline__ void test_triangles(const float *__restrict__ wtris, uint32_t first, uint32_t count, f3 org, f3 dir, int idx,
                                                float &tmin, int &best, uint32_t &best_tri, uint32_t &n_tri_u) {
-	const Tri2 *__restrict__ blk = reinterpret_cast<const Tri2 *>(wtris + (size_t)first * SRT_WTRI_FLOATS);
+	const float *__restrict__ blk = wtris + (size_t)first * SRT_WTRI_FLOATS;
 	const uint32_t npair = ((count + 3u) >> 2) << 1; // pairs, always even
-	Tri2 a = blk[0];
+	Tri2 a = ld_tri2(blk);
 	for (uint32_t b = 0; b < npair; b += 2) {
-		const Tri2 c = blk[b + 1]; // in flight while `a` is tested
+		const Tri2 c = ld_tri2(blk + 18u * (b + 1u)); // in flight while `a` is tested
 		test_pair<COUNT_TRIS>(a, org, dir, idx, 2u * b, count, tmin, best, best_tri, n_tri_u);
-		a = blk[b + 2];            // in flight while `c` is tested (one pair of slack is allocated past the end)
+		a = ld_tri2(blk + 18u * (b + 2u)); // in flight while `c` is tested (one pair of slack is allocated past the end)
 		test_pair<COUNT_TRIS>(c, org, dir, idx, 2u * b + 2u, count, tmin, best, best_tri, n_tri_u);
 	}
 }
@@ -585,13 +607,16 @@ __global__ __launch_bounds__(64, HAS_MODELS ? SRT_TRACE_WAVES_PER_SIMD_MODELS : 
 			if (HAS_MODELS) inv = mk(1.0f / dir.x, 1.0f / dir.y, 1.0f / dir.z);
 
 			for (int r = 0; r < p.num_runs; r++) {
-				const ShapeRun run = runs[r];
+				float rr[4];
+				ld_uniform<4, 16>(reinterpret_cast<const float *>(runs + r), rr);
+				ShapeRun run;
+				run.type = (int32_t)f2u(rr[0]), run.first_shape = f2u(rr[1]), run.count = f2u(rr[2]), run.data_off = f2u(rr[3]);
 				const float *__restrict__ d = run_data + run.data_off;
 				const int base = (int)run.first_shape;
 				const uint32_t cnt = run.count;
 				if (run.type == SRT_SHAPE_SPHERE) {
 					for (uint32_t k = 0; k < cnt; k += 4) {
-						const Blk16 b = *reinterpret_cast<const Blk16 *>(d + 4 * k);
+						const Blk16 b = ld_blk16(d + 4 * k);
 						test_sphere(b.v[0], b.v[1], b.v[2], b.v[3], org, dir, base + (int)k, tmin, best);
 						if (k + 1 < cnt) test_sphere(b.v[4], b.v[5], b.v[6], b.v[7], org, dir, base + (int)k + 1, tmin, best);
 						if (k + 2 < cnt) test_sphere(b.v[8], b.v[9], b.v[10], b.v[11], org, dir, base + (int)k + 2, tmin, best);
@@ -599,13 +624,13 @@ __global__ __launch_bounds__(64, HAS_MODELS ? SRT_TRACE_WAVES_PER_SIMD_MODELS : 
 					}
 				} else if (run.type == SRT_SHAPE_PLANE) {
 					for (uint32_t k = 0; k < cnt; k += 2) {
-						const Blk16 b = *reinterpret_cast<const Blk16 *>(d + 8 * k);
+						const Blk16 b = ld_blk16(d + 8 * k);
 						test_plane(b.v[0], b.v[1], b.v[2], b.v[4], b.v[5], b.v[6], org, dir, base + (int)k, tmin, best);
 						if (k + 1 < cnt) test_plane(b.v[8], b.v[9], b.v[10], b.v[12], b.v[13], b.v[14], org, dir, base + (int)k + 1, tmin, best);
 					}
 				} else if (HAS_MODELS && run.type == SRT_SHAPE_MODEL) {
 					for (uint32_t k = 0; k < cnt; k += 2) {
-						const Blk16 b = *reinterpret_cast<const Blk16 *>(d + 8 * k);
+						const Blk16 b = ld_blk16(d + 8 * k);
 						if (test_aabb(b.v[0], b.v[1], b.v[2], b.v[4], b.v[5], b.v[6], org, inv, tmin)) {
 							if (COUNT_TRIS) n_tri += f2u(b.v[7]);
 							test_triangles<COUNT_TRIS>(wtris, f2u(b.v[3]), f2u(b.v[7]), org, dir, base + (int)k, tmin, best, best_tri, n_tri_u);

@@ -453,8 +453,17 @@ int srt_trace(srt_tracer *t, const srt_render_data *options) {
 		if (fit < batch) batch = (uint32_t)fit;
 		if (batch > 4 && (batch & 3u)) batch &= ~3u; // keep the reduce kernel's 16-byte loads aligned
 	}
+	// allocate; if the device cannot give that much right now, fall back to smaller batches
+	while (batch) {
+		hipError_t e = t->radiance.reserve(pixels * (size_t)batch * 3 + 4);
+		if (e == hipSuccess) break;
+		(void)hipGetLastError(); // clear the sticky out-of-memory state
+		if (e != hipErrorOutOfMemory || batch == 1)
+			return fail(t, SRT_ERR_HIP, std::string("srt_trace: radiance buffer: ") + hipGetErrorString(e));
+		batch = batch > 8 ? ((batch / 2) & ~3u) : batch / 2;
+		t->radiance_budget = pixels * 12 * (size_t)batch;
+	}
 	const uint32_t n_batches = batch ? ((uint32_t)ns + batch - 1) / batch : 0u;
-	if (batch) SRT_HIP(t, t->radiance.reserve(pixels * (size_t)batch * 3 + 4));
 	if (n_batches > 1) SRT_HIP(t, t->running.reserve(pixels * 4));
 	p.radiance = t->radiance.ptr;
 	p.queue = t->counters.ptr + SRT_CTR_QUEUE;

@@ -464,9 +464,9 @@ __global__ __launch_bounds__(64, HAS_MODELS ? SRT_TRACE_WAVES_PER_SIMD_MODELS : 
 	// one fully coalesced burst of whole 64-byte lines when its last path has finished,
 	// instead of 12 scattered bytes per lane (which made the L2 fetch every line first).
 	unsigned long long chunk_cur = 0, chunk_end = 0;                 // wave-uniform
-	unsigned long long base0 = 0, base1 = 0, sub_q0 = 0;             // first item of the sub-job in buffer 0 / 1
+	unsigned long long base0 = 0, base1 = 0;                         // first item of the sub-job in buffer 0 / 1
 	uint32_t total0 = 0, total1 = 0;                                 // items of the sub-job staged in each buffer (0 = free)
-	uint32_t issued = 0, sub_k0 = 0, cur = 0;                        // issue cursor of the current buffer `cur`
+	uint32_t issued = 0, cur = 0;                                    // issue cursor of the current buffer `cur`
 	bool queue_dry = (total_items == 0);
 	float4 *__restrict__ stage = lds + p.stage_off; // [2][SRT_SUB] 16-byte slots: {dir.xyz, seed} before the trace, {r, g, b, -} after
 	float *__restrict__ ring = reinterpret_cast<float *>(stage + 2u * SRT_SUB); // [10][64] escaped paths awaiting their sky lookup
@@ -595,7 +595,7 @@ __global__ __launch_bounds__(64, HAS_MODELS ? SRT_TRACE_WAVES_PER_SIMD_MODELS : 
 		idle_spins = 0;
 
 		if (nb > 0) w_rays += (unsigned long long)__popcll(__ballot(active));
-		bool fin = false, missed = false;
+		bool missed = false;
 		if (active) {
 			bool done = (nb <= 0); // render.cl:403: no bounce loop at all -> colour 0
 			if (!done) {
@@ -764,11 +764,9 @@ __global__ __launch_bounds__(64, HAS_MODELS ? SRT_TRACE_WAVES_PER_SIMD_MODELS : 
 			if (done) {
 				stage[bi * (uint32_t)SRT_SUB + slot] = make_float4(color.x, color.y, color.z, 0.f);
 				active = false;
-				fin = true;
 			}
 		}
 
-		(void)fin;
 		// ---- deferred sky: queue this iteration's escaped paths (wave-uniform control flow) ----
 		const unsigned long long mm = __ballot(missed);
 		if (mm != 0ull) {

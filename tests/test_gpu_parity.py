@@ -313,3 +313,36 @@ def test_async_progressive_frames_equal_blocking_frames(T, sky):
     assert np.array_equal(outs[-1].reshape(g["argb"].shape), g["argb"])
     assert not np.array_equal(outs[0], outs[-1])  # earlier frames were really delivered separately
     t.close()
+
+
+def test_caller_owned_canvas_stream_and_external_resolve(T, sky):
+    """The zero-copy hand-off bench.py relies on: canvas in a torch tensor (srt_bind_canvas),
+    launches on a torch stream (srt_bind_stream), resolve of a caller-owned buffer
+    (srt_resolve_external), device pointers reported by srt_device_buffers."""
+    import torch
+    g = CASES["mixed"]
+    w, h = int(g["rd"]["width"]), int(g["rd"]["height"])
+    dev = torch.device("cuda", 0)
+    stream = torch.cuda.Stream(device=dev)
+    with torch.cuda.stream(stream):
+        t = make_tracer(T, g, sky)
+        t.bind_stream(stream.cuda_stream)
+        canvas = torch.zeros((h, w, 4), dtype=torch.float32, device=dev)
+        t.bind_canvas(canvas.data_ptr(), canvas.numel() * 4)
+        cp, cb, ap, ab = t.device_buffers()
+        assert cp == canvas.data_ptr() and cb == canvas.numel() * 4 and ap and ab >= w * h * 4
+        t.clear_canvas()
+        t.trace()
+        argb = torch.zeros((h, w, 4), dtype=torch.uint8, device=dev)
+        t.resolve_external(canvas.data_ptr(), w * h, 1, argb.data_ptr())
+        stream.synchronize()
+        assert bits_equal(canvas.cpu().numpy(), g["canvas"])
+        assert np.array_equal(argb.cpu().numpy(), g["argb"])
+        with pytest.raises(T.SrtError):
+            t.bind_canvas(canvas.data_ptr(), 16)  # too small for the owned rows
+        t.bind_canvas(0, 0)                        # back to the handle's own canvas
+        t.bind_stream(0)
+        t.clear_canvas()
+        t.trace()
+        assert bits_equal(t.read_canvas(), g["canvas"])
+        t.close()

@@ -158,8 +158,10 @@ int srt_partition_unpermute(const void *gathered, void *image, int height, int w
  * all 2^32 RNG outputs: out[0..2] = mismatch counts of the kernel-local sqrt / log / cos
  * specialisations against their generic definitions (must be 0); out[3..7] = sums of the
  * result bit patterns of detmath's log, cos, sqrt, atan2pi, pow on the device, to be
- * compared with the same sums from the host build of csrc/detmath.h. */
-int srt_selftest_math(srt_tracer *t, uint32_t stride, uint64_t out[8]);
+ * compared with the same sums from the host build of csrc/detmath.h; out[8..10] = mismatch
+ * counts of the kernel's shared-reciprocal division, its normalize and its unguarded
+ * Box-Muller square root against IEEE `/` and sqrt (must be 0); out[11] = 0. */
+int srt_selftest_math(srt_tracer *t, uint32_t stride, uint64_t out[12]);
 
 /* Library / build identification, e.g. "srt-hip gfx950 parity fp-contract=off". */
 const char *srt_version(void);

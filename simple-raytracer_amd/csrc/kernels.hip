@@ -73,7 +73,80 @@ __device__ __forceinline__ float sqrt_ieee(float x) {
 	return dm_sqrtf(x);
 #endif
 }
-__device__ __forceinline__ f3 normalize3(f3 a) { return a / sqrt_ieee(dot3(a, a)); }
+// sqrt_ieee without its slow-path guard, for arguments known to be 0, inf, NaN or of
+// magnitude >= 2^-96.
+__device__ __forceinline__ float sqrt_core(float x) {
+#ifndef SRT_NO_FAST_SQRT
+	float s = __builtin_amdgcn_sqrtf(x);
+	const uint32_t si = dm_f2u(s);
+	float down = dm_u2f(si - 1u), up = dm_u2f(si + 1u);
+	float vp = __builtin_fmaf(-down, s, x);
+	float vs = __builtin_fmaf(-up, s, x);
+	s = (vp <= 0.0f) ? down : s;
+	s = (vs > 0.0f) ? up : s;
+	return s;
+#else
+	return dm_sqrtf(x);
+#endif
+}
+
+// ---- IEEE division with the operand scaling factored out ------------------------------
+// hipcc expands a / b into v_div_scale (x2), v_rcp, two Newton steps on the reciprocal,
+// q = a*r with two residual corrections, v_div_fmas and v_div_fixup: 11 instructions, one
+// of them transcendental, per quotient. v_div_scale / v_div_fmas only rescale by 2^+-64 when
+// an operand or the quotient comes near the ends of the exponent range, and v_div_fixup only
+// replaces the result for zero / inf / NaN operands and out-of-range quotients (CDNA3 ISA
+// guide, V_DIV_SCALE_F32 / V_DIV_FIXUP_F32). For
+//     2^-40 <= |b| <= 2^40   and   2^-60 <= |a| <= 2^50
+// none of those cases applies (both normal, exponent(a) > 23, -126 < e_a - e_b < 96, 1/b
+// normal), so the expansion reduces to the plain sequence below, bit for bit -- and its
+// first three instructions depend on b alone, so quotients that share a denominator share
+// them. Outside that box the compiler's division runs. A NaN numerator gives NaN either way.
+// srt_selftest_math compares both against `/` on the device (out[8], out[9]).
+__device__ __forceinline__ float rcp_refined(float b) {
+	float r = __builtin_amdgcn_rcpf(b);
+	float e = __builtin_fmaf(-b, r, 1.0f);
+	return __builtin_fmaf(e, r, r);
+}
+__device__ __forceinline__ float div_core(float a, float b, float r) {
+	float q = a * r;
+	float m = __builtin_fmaf(-b, q, a);
+	q = __builtin_fmaf(m, r, q);
+	m = __builtin_fmaf(-b, q, a);
+	return __builtin_fmaf(m, r, q);
+}
+__device__ __forceinline__ bool div_num_ok(f3 a) {
+	const float ax = dm_fabs(a.x), ay = dm_fabs(a.y), az = dm_fabs(a.z);
+	const float mn = __builtin_fminf(__builtin_fminf(ax, ay), az); // v_min3 / v_max3: skip NaNs
+	const float mx = __builtin_fmaxf(__builtin_fmaxf(ax, ay), az);
+	return mn >= 0x1p-60f && mx <= 0x1p50f;
+}
+// a / b, component-wise
+__device__ __forceinline__ f3 div3(f3 a, float b) {
+#ifndef SRT_NO_FAST_DIV
+	const float ab = dm_fabs(b);
+	if (__builtin_expect(div_num_ok(a) && ab >= 0x1p-40f && ab <= 0x1p40f, 1)) {
+		const float r = rcp_refined(b);
+		return mk(div_core(a.x, b, r), div_core(a.y, b, r), div_core(a.z, b, r));
+	}
+#endif
+	return a / b;
+}
+// a / sqrt(dot(a, a)); 2^-80 <= d <= 2^80 puts the length in [2^-40, 2^40] and lets the
+// square root skip its own small-argument guard. No component exceeds the length by more
+// than rounding, so only the smallest one needs a look.
+__device__ __forceinline__ f3 normalize3(f3 a) {
+	const float d = dot3(a, a);
+#ifndef SRT_NO_FAST_DIV
+	const float mn = __builtin_fminf(__builtin_fminf(dm_fabs(a.x), dm_fabs(a.y)), dm_fabs(a.z));
+	if (__builtin_expect(mn >= 0x1p-60f && d >= 0x1p-80f && d <= 0x1p80f, 1)) {
+		const float b = sqrt_core(d);
+		const float r = rcp_refined(b);
+		return mk(div_core(a.x, b, r), div_core(a.y, b, r), div_core(a.z, b, r));
+	}
+#endif
+	return a / sqrt_ieee(d);
+}
 __device__ __forceinline__ f3 mix3(f3 x, f3 y, float a) {
 	return mk(dm_mix(x.x, y.x, a), dm_mix(x.y, y.y, a), dm_mix(x.z, y.z, a));
 }
@@ -111,7 +184,14 @@ __device__ __forceinline__ float log_unit(float u) {
 	float x = dm_u2f(ix | (i ^ 0x3f800000u));
 	k += (int)(i >> 23);
 	float f = x - 1.0f;
-	float s = f / (2.0f + f);
+	// f is +0 or a multiple of 2^-24 in [-0.293, 0.415] and 2 + f lies in [1.7, 2.42]: inside the
+	// box of div_core (which also returns the +0 the division gives for f = +0)
+	const float den = 2.0f + f;
+#ifndef SRT_NO_FAST_DIV
+	float s = div_core(f, den, rcp_refined(den));
+#else
+	float s = f / den;
+#endif
 	float z = s * s;
 	float R = z * (L0 + z * (L1 + z * (L2 + z * L3)));
 	float hfsq = (0.5f * f) * f;
@@ -143,7 +223,8 @@ __device__ __forceinline__ float cos_2pi(float x) {
 // Box-Muller, theta drawn first (render.cl:150-154)
 __device__ __forceinline__ float random_normal(uint32_t &seed) {
 	float theta = 6.28318548f * random_float(seed);
-	float rho = sqrt_ieee(-2.0f * log_unit(random_float(seed)));
+	// -2 log u is -0, +inf or in [1.19e-7, 44.4] for every u random_float can return: no small-argument guard
+	float rho = sqrt_core(-2.0f * log_unit(random_float(seed)));
 	return rho * cos_2pi(theta);
 }
 
@@ -669,7 +750,7 @@ __global__ __launch_bounds__(64, HAS_MODELS ? SRT_TRACE_WAVES_PER_SIMD_MODELS : 
 				}
 				pos = org + dir * tmin;
 				if (type == SRT_SHAPE_SPHERE) {
-					nrm = (pos - wv) / ww;
+					nrm = div3(pos - wv, ww);
 				} else if (type == SRT_SHAPE_PLANE) {
 					nrm = wv;
 				} else if (HAS_MODELS) {
@@ -916,14 +997,30 @@ __global__ __launch_bounds__(256) void srt_resolve_kernel(const ResolveParams p)
 //   out[2] cos_2pi(t) != dm_cosf(t), t = 2pi*u    out[3] sum of bits of dm_logf(u)
 //   out[4] sum of bits of dm_cosf(t)              out[5] sum of bits of sqrt(u)
 //   out[6] sum of bits of dm_atan2pif(u - 0.5, 0.37 - u)   out[7] sum of bits of dm_powf(u, 25)
+//   out[8] div3(a, b) != a / b          out[9] normalize3(a) != a / sqrt(dot(a, a))
+//          (a, b: random mantissas and signs, exponents straddling the fast paths' guards,
+//           zero components mixed in)
+//   out[10] sqrt_core(-2 log_unit(u)) != IEEE sqrt, the one call site without a guard
 // ---------------------------------------------------------------------------------
 namespace {
 __device__ __forceinline__ bool same_float(float a, float b) { return (a != a && b != b) || dm_f2u(a) == dm_f2u(b); }
 __device__ __forceinline__ unsigned long long canon_bits(float a) { return (a != a) ? 0x7fc00000ull : (unsigned long long)dm_f2u(a); }
+__device__ __forceinline__ uint32_t mix32(uint32_t &h) {
+	h = h * 747796405u + 2891336453u;
+	uint32_t r = ((h >> ((h >> 28) + 4u)) ^ h) * 277803737u;
+	return (r >> 22) ^ r;
+}
+// random sign and mantissa, biased exponent uniform in [lo, lo + span)
+__device__ __forceinline__ float rand_float_exp(uint32_t &h, uint32_t lo, uint32_t span) {
+	const uint32_t m = mix32(h), e = lo + mix32(h) % span;
+	return dm_u2f((m & 0x807fffffu) | (e << 23));
+}
+__device__ __forceinline__ bool same_f3(f3 a, f3 b) { return same_float(a.x, b.x) && same_float(a.y, b.y) && same_float(a.z, b.z); }
 } // namespace
 
 __global__ __launch_bounds__(256) void srt_selftest_kernel(unsigned long long *out, uint32_t stride) {
 	unsigned long long bad_sqrt = 0, bad_log = 0, bad_cos = 0, s_log = 0, s_cos = 0, s_sqrt = 0, s_atan = 0, s_pow = 0;
+	unsigned long long bad_div = 0, bad_norm = 0, bad_rn = 0;
 	const unsigned long long total = (0x100000000ull + stride - 1) / stride;
 	for (unsigned long long i = blockIdx.x * (unsigned long long)blockDim.x + threadIdx.x; i < total;
 	     i += (unsigned long long)gridDim.x * blockDim.x) {
@@ -941,6 +1038,18 @@ __global__ __launch_bounds__(256) void srt_selftest_kernel(unsigned long long *o
 		s_sqrt += canon_bits(dm_sqrtf(u));
 		s_atan += canon_bits(dm_atan2pif(u - 0.5f, 0.37f - u));
 		s_pow += canon_bits(dm_powf(u, 25.0f));
+		const float arg = -2.0f * lg;
+		bad_rn += same_float(sqrt_core(arg), __builtin_sqrtf(arg)) ? 0 : 1;
+		// guards: numerators 2^-60 .. 2^50, denominator 2^-40 .. 2^40, squared length 2^-80 .. 2^80
+		uint32_t h = r ^ 0x9e3779b9u;
+		f3 a = mk(rand_float_exp(h, 127 - 64, 118), rand_float_exp(h, 127 - 64, 118), rand_float_exp(h, 127 - 64, 118));
+		if ((r & 15u) == 3u) a.x = 0.0f;
+		if ((r & 31u) == 5u) a.y = -0.0f;
+		if ((r & 0xfffu) == 7u) a.z = dm_u2f(mix32(h)); // any bit pattern: denormals, inf, NaN
+		const float b = rand_float_exp(h, 127 - 44, 88);
+		bad_div += same_f3(div3(a, b), a / b) ? 0 : 1;
+		const f3 c = mk(rand_float_exp(h, 127 - 64, 108), a.y, a.z); // keeps dot(c, c) finite most of the time
+		bad_norm += same_f3(normalize3(c), c / __builtin_sqrtf(dot3(c, c))) ? 0 : 1;
 	}
 	atomicAdd(&out[0], bad_sqrt);
 	atomicAdd(&out[1], bad_log);
@@ -950,6 +1059,9 @@ __global__ __launch_bounds__(256) void srt_selftest_kernel(unsigned long long *o
 	atomicAdd(&out[5], s_sqrt);
 	atomicAdd(&out[6], s_atan);
 	atomicAdd(&out[7], s_pow);
+	atomicAdd(&out[8], bad_div);
+	atomicAdd(&out[9], bad_norm);
+	atomicAdd(&out[10], bad_rn);
 }
 
 void srt_launch_selftest(unsigned long long *out, uint32_t stride, void *stream) {

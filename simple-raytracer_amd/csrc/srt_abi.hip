@@ -710,23 +710,23 @@ int srt_set_partition(srt_tracer *t, int rank, int world, int rows_per_block) {
 	return clear_canvas_impl(t);
 }
 
-int srt_selftest_math(srt_tracer *t, uint32_t stride, uint64_t out[8]) {
+int srt_selftest_math(srt_tracer *t, uint32_t stride, uint64_t out[12]) {
 	if (!t) return SRT_ERR_INVALID;
 	if (!out || stride == 0) return fail(t, SRT_ERR_INVALID, "srt_selftest_math: bad arguments");
 	SRT_HIP(t, hipSetDevice(t->device));
 	unsigned long long *d = nullptr;
-	SRT_HIP(t, hipMalloc(reinterpret_cast<void **>(&d), 8 * sizeof(unsigned long long)));
-	hipError_t e = hipMemsetAsync(d, 0, 8 * sizeof(unsigned long long), t->stream);
+	SRT_HIP(t, hipMalloc(reinterpret_cast<void **>(&d), 12 * sizeof(unsigned long long)));
+	hipError_t e = hipMemsetAsync(d, 0, 12 * sizeof(unsigned long long), t->stream);
 	if (e == hipSuccess) {
 		srt_launch_selftest(d, stride, t->stream);
 		e = hipGetLastError();
 	}
-	unsigned long long h[8] = {0};
+	unsigned long long h[12] = {0};
 	if (e == hipSuccess) e = hipMemcpyAsync(h, d, sizeof h, hipMemcpyDeviceToHost, t->stream);
 	if (e == hipSuccess) e = hipStreamSynchronize(t->stream);
 	(void)hipFree(d);
 	if (e != hipSuccess) return fail(t, SRT_ERR_HIP, std::string("srt_selftest_math: ") + hipGetErrorString(e));
-	for (int i = 0; i < 8; i++) out[i] = h[i];
+	for (int i = 0; i < 12; i++) out[i] = h[i];
 	return SRT_OK;
 }
 

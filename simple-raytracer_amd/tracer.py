@@ -203,7 +203,7 @@ class Tracer:
         self._check(self.lib.srt_set_count_triangles(self._h, 1 if enable else 0))
 
     def selftest_math(self, stride=1):
-        out = (C.c_uint64 * 8)()
+        out = (C.c_uint64 * 12)()
         self._check(self.lib.srt_selftest_math(self._h, stride, out))
         return [int(v) for v in out]
 

@@ -203,10 +203,13 @@ def test_device_math_equals_host_math(T, oracle):
     assert full[0] == 0, f"sqrt_ieee differs from IEEE sqrt on {full[0]} of 2^32 bit patterns"
     assert full[1] == 0, f"log_unit differs from dm_logf on {full[1]} RNG outputs"
     assert full[2] == 0, f"cos_2pi differs from dm_cosf on {full[2]} RNG outputs"
+    assert full[8] == 0, f"div3 differs from IEEE division on {full[8]} of 2^32 random operand sets"
+    assert full[9] == 0, f"normalize3 differs from a / sqrt(dot(a, a)) on {full[9]} of 2^32 random vectors"
+    assert full[10] == 0, f"unguarded Box-Muller sqrt differs from IEEE sqrt on {full[10]} RNG outputs"
     dev = t.selftest_math(61)
     host = oracle.math_checksums(61)
-    assert dev[:3] == [0, 0, 0]
-    assert dev[3:] == host[3:], (dev, host)
+    assert dev[:3] == [0, 0, 0] and dev[8:11] == [0, 0, 0]
+    assert dev[3:8] == host[3:8], (dev, host)
     t.close()
 
 

@@ -4,6 +4,11 @@
 arithmetic (DESIGN.md "Numerics"). hipcc's defaults -fhip-fp32-correctly-rounded-
 divide-sqrt and f32 denormal support stay ON (never pass -ffast-math,
 -fgpu-flush-denormals-to-zero or -fno-hip-fp32-correctly-rounded-divide-sqrt here).
+
+-fno-slp-vectorize: the SLP vectoriser pairs scalar float ops into v_pk_mul/add_f32. On
+gfx950 a packed fp32 op issues at half the rate of a plain one, so nothing is gained, and
+assembling the register pairs costs v_mov's: measured -11 % (spheres) to -19 % (meshes)
+trace time with it off (profiles/README.md). It reorders nothing, so results are unchanged.
 """
 import contextlib
 import fcntl
@@ -19,7 +24,7 @@ LIB = LIBDIR / "libsrt_hip.so"
 SOURCES = ["kernels.hip", "srt_abi.hip"]
 HEADERS = ["detmath.h", "device_types.h", "../../include/srt_abi.h", "../../include/srt_types.h"]
 ARCH = "gfx950"
-FLAGS = ["-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-fno-gpu-rdc", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function"]
+FLAGS = ["-O3", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize", "-fPIC", "-fno-gpu-rdc", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function"]
 
 
 def hipcc():

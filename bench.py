@@ -111,6 +111,8 @@ def main():
     ap.add_argument("--spp", type=int, default=0, help="override samples per pixel (development only; makes the line non-comparable)")
     ap.add_argument("--rows-per-block", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--accel", default="none", choices=["none", "bvh"],
+                    help="bvh = opt-in acceleration structure for model shapes (srt_set_acceleration); the headline line uses none")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo = REHEARSAL ONLY on a box with fewer GPUs than ranks: ranks share cuda:0 and the gather is staged through host memory")
     args = ap.parse_args()
@@ -153,6 +155,8 @@ def main():
     t.set_skybox(sky)
     t.options = R.render_data(w, h, spp, nb, camera_to_world=S.default_camera(), time=12345)
     t.scene_data = R.scene_data(len(shapes))
+    if args.accel == "bvh":
+        t.set_acceleration(T.ACCEL_BVH)
     t.update_scene(shapes, tris, mats)
     part = multi.RowPartition(h, rank, world, args.rows_per_block)
     canvas_t = torch.zeros((part.padded, w, 4), dtype=torch.float32, device=dev)
@@ -224,7 +228,7 @@ def main():
         ref_t = T.Tracer(w, h, device=local_rank)
         ref_t.set_skybox(sky)
         ref_t.options, ref_t.scene_data = t.options.copy(), t.scene_data.copy()
-        ref_t.update_scene(shapes, tris, mats)
+        ref_t.update_scene(shapes, tris, mats)  # array-order scan even when the ranks use the BVH
         ref_t.clear_canvas()
         ref_t.trace()
         want = ref_t.read_canvas()
@@ -271,7 +275,8 @@ def main():
             "data": "synthetic",
             "config": {"workload": desc + (f" [spp overridden to {spp}]" if args.spp else ""), "width": w, "height": h, "spp": spp,
                        "bounces": nb, "shapes": int(len(shapes)), "triangles": int(len(tris)), "partition": f"{world} x interleaved {args.rows_per_block}-row blocks" if world > 1 else "single GPU",
-                       "mode": "parity (fp-contract off, IEEE div/sqrt; canvas bit-identical to the CPU oracle)"},
+                       "mode": "parity (fp-contract off, IEEE div/sqrt; canvas bit-identical to the CPU oracle)",
+                       **({"accel": {"kind": "bvh", **t.acceleration_info(), "note": "triangle counters are the BVH walk's leaf tests; node box tests are not in W_ops"}} if args.accel == "bvh" else {})},
             "mpath_per_s": round(paths / elapsed_max / 1e6, 2),
             "rays_per_step": per["rays"], "paths_per_step": per["paths"], "nan_pixels": nan_px,
             "kernel_ms": {"srt_trace_kernel": round(trace_ms_max, 3),

@@ -72,6 +72,23 @@ int srt_update_scene(srt_tracer *t, const srt_shape *shapes, size_t n_shapes, co
                      size_t n_triangles, const srt_material *materials, size_t n_materials,
                      const srt_scene_data *scene);
 
+/* Acceleration structure for model shapes (new; the reference's first "future plan",
+ * README.md:41). Takes effect at the NEXT srt_update_scene.
+ *   SRT_ACCEL_NONE (default): every triangle of a model whose box the ray enters is tested
+ *       in array order, as render.cl:329-345 -- the parity mode.
+ *   SRT_ACCEL_BVH: srt_update_scene builds one bounding-volume hierarchy per model instance
+ *       (host, binned SAH) and rays walk it instead of the array. Same triangle test, same
+ *       first-in-array-order rule for hits of equal distance, conservative (padded) boxes:
+ *       the canvas equals SRT_ACCEL_NONE's except where a grazing ray's rounding error puts
+ *       an accepted hit outside its triangle's padded box (not observed on the test scenes;
+ *       tests/test_gpu_bvh.py). Spheres, planes and each model's own AABB test are untouched. */
+#define SRT_ACCEL_NONE 0
+#define SRT_ACCEL_BVH 1
+int srt_set_acceleration(srt_tracer *t, int mode);
+/* out = {nodes, leaves, depth, host build time in microseconds} of the current scene's
+ * hierarchies (zeros without SRT_ACCEL_BVH or without models). */
+int srt_acceleration_info(const srt_tracer *t, uint64_t out[4]);
+
 /* Tracer::clear_canvas — src/tracer.cpp:98-101. */
 int srt_clear_canvas(srt_tracer *t);
 

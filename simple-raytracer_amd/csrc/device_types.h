@@ -15,6 +15,7 @@
  *   sphere: 4 dwords  {cx, cy, cz, r*r}                    -> 4 spheres per s_load_dwordx16
  *   plane : 8 dwords  {px, py, pz, 0, nx, ny, nz, 0}       -> 2 planes per s_load_dwordx16
  *   model : 8 dwords  {min.x, min.y, min.z, first_wtri(bits), max.x, max.y, max.z, count(bits)}
+ *           (with a BVH: the root node's index in place of first_wtri)
  * data_off is in dwords into the packed array and is a multiple of 16 (64 B). */
 struct ShapeRun {
 	int32_t type;
@@ -40,6 +41,27 @@ static_assert(sizeof(WinnerRec) == 32, "WinnerRec 32 B");
  * v = transform * pos in the operation order of render.cl:114-120, so each value is
  * bit-identical to what the reference recomputes per ray (render.cl:325-328,247-248). */
 #define SRT_WTRI_FLOATS 9
+
+/* Optional acceleration structure (srt_set_acceleration, include/srt_abi.h; SURVEY.md 8(f)
+ * row 4). One binary BVH per model instance over its world-space triangles, built on the
+ * host at srt_update_scene. Nodes are stored in depth-first order and carry a SKIP link (the
+ * node that follows their subtree), so a lane walks the tree with one index and no stack:
+ *     box hit, inner -> node + 1        box hit, leaf -> test its triangles, then skip
+ *     box missed     -> skip            SRT_BVH_END ends the walk
+ * Indices only ever grow, so every walk ends after at most `node count` steps.
+ * Triangles are re-ordered so that a leaf's triangles are consecutive 48-byte records
+ * {v0, e1, e2, j, 0, 0} (j = index inside the model, for the reference's first-in-array-
+ * order tie rule and for the vertex normals), values as in SRT_WTRI_FLOATS above. */
+struct BvhNode {
+	float lo[3];
+	uint32_t skip;
+	float hi[3];
+	uint32_t leaf; /* 0: inner node; else (count << 28) | first record (absolute) */
+};
+static_assert(sizeof(BvhNode) == 32, "BvhNode 32 B");
+#define SRT_BVH_END 0xffffffffu
+#define SRT_BVH_TRI_FLOATS 12
+#define SRT_BVH_LEAF_MAX 4
 
 enum { SRT_CTR_RAYS = 0, SRT_CTR_SKY, SRT_CTR_TRI, SRT_CTR_TRI_PASS_U, SRT_CTR_NAN, SRT_CTR_PATHS, SRT_CTR_QUEUE, SRT_CTR_WATCHDOG, SRT_CTR_COUNT };
 
@@ -75,6 +97,9 @@ struct TraceParams {
 	int32_t _pad2;
 	int32_t num_models;
 	int32_t rank, world, rows_per_block, owned_rows;
+	int32_t use_bvh;          /* model records carry a BVH root instead of a first world triangle */
+	const BvhNode *bvh_nodes; /* all models' nodes; links are absolute indices */
+	const float *bvh_tris;    /* SRT_BVH_TRI_FLOATS per record, leaf order */
 };
 
 struct PrepassParams {
@@ -84,6 +109,7 @@ struct PrepassParams {
 	float *wtris;
 	int32_t num_shapes;
 	uint32_t num_triangles; /* size of the triangle array, for bounds clamping */
+	const uint32_t *order;  /* BVH layout: record wtri_offset[shape] + s holds triangle order[wtri_offset[shape] + s]; NULL = array order, 9 floats */
 };
 
 /* Ordered reduction of a batch: per pixel, colour += radiance[pixel][k] for k in order
@@ -113,6 +139,6 @@ int srt_trace_waves_per_simd(int has_models);
 int srt_sub_job_items(int has_models); /* items per LDS-staged sub-job; chunks per atomic are multiples of it */
 void srt_launch_prepass(const PrepassParams &p, uint64_t total_wtris, void *stream);
 void srt_launch_resolve(const ResolveParams &p, void *stream);
-void srt_launch_selftest(unsigned long long *out8, uint32_t stride, void *stream);
+void srt_launch_selftest(unsigned long long *out12, uint32_t stride, void *stream);
 
 #endif

@@ -325,10 +325,10 @@ __device__ __forceinline__ bool test_aabb(float lx, float ly, float lz, float hx
 // 2^-10 dwarf the 2^-22 worst-case relative error of fl(1/a)*sh; NaNs compare false and
 // fall through). Lanes not rejected run the reference's exact sequence; the wave skips
 // it when no lane is left (s_cbranch_execz). Results are therefore bit-identical.
+// Returns true when the reference accepts the triangle; t is then its hit distance.
 template <bool COUNT_TRIS>
-__device__ __forceinline__ void test_triangle(float v0x, float v0y, float v0z, float e1x, float e1y, float e1z, float e2x, float e2y,
-                                              float e2z, f3 org, f3 dir, int idx, uint32_t j, uint32_t count, float &tmin, int &best,
-                                              uint32_t &best_tri, uint32_t &n_tri_u) {
+__device__ __forceinline__ bool moller_trumbore(float v0x, float v0y, float v0z, float e1x, float e1y, float e1z, float e2x, float e2y,
+                                                float e2z, f3 org, f3 dir, bool counted, float &t, uint32_t &n_tri_u) {
 	f3 e1 = mk(e1x, e1y, e1z), e2 = mk(e2x, e2y, e2z);
 	f3 h = cross3(dir, e2);
 	float a = dot3(e1, h);
@@ -336,21 +336,30 @@ __device__ __forceinline__ void test_triangle(float v0x, float v0y, float v0z, f
 	float sh = dot3(sv, h);
 	float aa = dm_fabs(a), ash = dm_fabs(sh);
 	bool reject = (a == 0.0f) || (ash > aa * 1.001f) || ((sh * a < 0.0f) && (ash >= aa * 0.001f));
+	bool ok = false;
 	if (!reject) {
 		float f = 1.0f / a;
 		float u = f * sh;
-		bool ok = !(u < 0.0f || u > 1.0f);
-		if (COUNT_TRIS) n_tri_u += (ok && j < count) ? 1u : 0u; // padding triangles (NaN rays reach here) are not tests
+		ok = !(u < 0.0f || u > 1.0f);
+		if (COUNT_TRIS) n_tri_u += (ok && counted) ? 1u : 0u; // padding triangles (NaN rays reach here) are not tests
 		f3 q = cross3(sv, e1);
 		float v = f * dot3(dir, q);
 		ok = ok && !(v < 0.0f || u + v > 1.0f);
-		float t = f * dot3(e2, q);
+		t = f * dot3(e2, q);
 		ok = ok && t > 0.0f;
-		if (ok && t < tmin) {
-			tmin = t;
-			best = idx;
-			best_tri = j;
-		}
+	}
+	return ok;
+}
+
+template <bool COUNT_TRIS>
+__device__ __forceinline__ void test_triangle(float v0x, float v0y, float v0z, float e1x, float e1y, float e1z, float e2x, float e2y,
+                                              float e2z, f3 org, f3 dir, int idx, uint32_t j, uint32_t count, float &tmin, int &best,
+                                              uint32_t &best_tri, uint32_t &n_tri_u) {
+	float t = 0.0f;
+	if (moller_trumbore<COUNT_TRIS>(v0x, v0y, v0z, e1x, e1y, e1z, e2x, e2y, e2z, org, dir, j < count, t, n_tri_u) && t < tmin) {
+		tmin = t;
+		best = idx;
+		best_tri = j;
 	}
 }
 
@@ -381,6 +390,57 @@ __device__ __forceinline__ void test_triangles(const float *__restrict__ wtris, 
 		test_pair<COUNT_TRIS>(a, org, dir, idx, 2u * b, count, tmin, best, best_tri, n_tri_u);
 		a = ld_tri2(blk + 18u * (b + 2u)); // in flight while `c` is tested (one pair of slack is allocated past the end)
 		test_pair<COUNT_TRIS>(c, org, dir, idx, 2u * b + 2u, count, tmin, best, best_tri, n_tri_u);
+	}
+}
+
+// ---- BVH walk (opt-in; device_types.h BvhNode) -------------------------------------------
+// Per lane: rays of a wave are incoherent after the first bounce, so nodes and triangles come
+// through per-lane loads (the tree of a 10^5-triangle model is ~5 MB: L2 / Infinity Cache
+// resident). Same Moller-Trumbore as the brute-force loop, so every accepted hit has the same
+// t; what the walk must guarantee is that the triangle the array-order scan would settle on
+// is visited and wins:
+//  * boxes were padded on the host and the slab test below errs towards "hit" (safe inverse
+//    for zero direction components, relative slack on the exit distance);
+//  * the scan keeps the FIRST triangle of equal t (strict <, render.cl:254-256): a hit with
+//    t == tmin inside the same model replaces the incumbent only if its index j is lower.
+template <bool COUNT_TRIS>
+__device__ __forceinline__ void walk_bvh(const BvhNode *__restrict__ nodes, const float *__restrict__ recs, uint32_t root, f3 org, f3 dir, int idx,
+                                         float &tmin, int &best, uint32_t &best_rec, uint32_t &best_j, uint32_t &n_tri, uint32_t &n_tri_u) {
+	// 1/d, or +-2^100 where |d| < 2^-100: (lo - o) * inv stays finite (no 0 * inf = NaN), and keeps its sign
+	f3 inv;
+	inv.x = dm_fabs(dir.x) >= 0x1p-100f ? 1.0f / dir.x : __builtin_copysignf(0x1p100f, dir.x);
+	inv.y = dm_fabs(dir.y) >= 0x1p-100f ? 1.0f / dir.y : __builtin_copysignf(0x1p100f, dir.y);
+	inv.z = dm_fabs(dir.z) >= 0x1p-100f ? 1.0f / dir.z : __builtin_copysignf(0x1p100f, dir.z);
+	const float4 *__restrict__ n4 = reinterpret_cast<const float4 *>(nodes);
+	const float4 *__restrict__ r4 = reinterpret_cast<const float4 *>(recs);
+	uint32_t node = root;
+	while (node != SRT_BVH_END) {
+		const float4 a = n4[2u * node], b = n4[2u * node + 1u];
+		const float x1 = (a.x - org.x) * inv.x, x2 = (b.x - org.x) * inv.x;
+		const float y1 = (a.y - org.y) * inv.y, y2 = (b.y - org.y) * inv.y;
+		const float z1 = (a.z - org.z) * inv.z, z2 = (b.z - org.z) * inv.z;
+		const float tn = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(x1, x2), __builtin_fminf(y1, y2)), __builtin_fmaxf(__builtin_fminf(z1, z2), 0.0f));
+		const float tf = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(x1, x2), __builtin_fmaxf(y1, y2)), __builtin_fminf(__builtin_fmaxf(z1, z2), tmin));
+		const bool inside = tn <= tf * 1.000001f;
+		const uint32_t skip = f2u(a.w), leaf = f2u(b.w);
+		if (inside && leaf != 0u) {
+			const uint32_t first = leaf & 0x0fffffffu, cnt = leaf >> 28;
+			if (COUNT_TRIS) n_tri += cnt;
+			for (uint32_t k = 0; k < cnt; k++) {
+				const float4 q0 = r4[3u * (first + k)], q1 = r4[3u * (first + k) + 1u], q2 = r4[3u * (first + k) + 2u];
+				float t = 0.0f;
+				if (moller_trumbore<COUNT_TRIS>(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, org, dir, true, t, n_tri_u)) {
+					const uint32_t j = f2u(q2.y);
+					if (t < tmin || (t == tmin && best == idx && j < best_j)) {
+						tmin = t;
+						best = idx;
+						best_rec = first + k;
+						best_j = j;
+					}
+				}
+			}
+		}
+		node = (inside && leaf == 0u) ? node + 1u : skip;
 	}
 }
 
@@ -509,7 +569,7 @@ __device__ __forceinline__ void flush_stage(const float *__restrict__ src, float
 // HAS_MODELS = false compiles every AABB / triangle / mesh-normal path out: scenes of
 // spheres and planes (BASELINE configs 0, 1, 3) get a leaner kernel (fewer registers, no
 // spills, smaller code); the host picks the instantiation from the scene.
-template <bool COUNT_TRIS, bool USE_LDS, bool HAS_MODELS>
+template <bool COUNT_TRIS, bool USE_LDS, bool HAS_MODELS, bool USE_BVH>
 __global__ __launch_bounds__(64, HAS_MODELS ? SRT_TRACE_WAVES_PER_SIMD_MODELS : SRT_TRACE_WAVES_PER_SIMD) void srt_trace_kernel(const TraceParams p) {
 	extern __shared__ float4 lds[]; // [2*n_shapes] winner records, [4*n_materials] materials, [2][SRT_SUB] staging slots
 	constexpr uint32_t SRT_SUB = HAS_MODELS ? SRT_SUB_MODELS : SRT_SUB_PLAIN;
@@ -683,7 +743,8 @@ __global__ __launch_bounds__(64, HAS_MODELS ? SRT_TRACE_WAVES_PER_SIMD_MODELS : 
 			// ---- closest_intersection (render.cl:293-378), winner deferred ----
 			float tmin = DM_INF_F;
 			int best = -1;
-			uint32_t best_tri = 0;
+			uint32_t best_tri = 0; // index inside the model; with a BVH: absolute triangle record
+			uint32_t best_j = 0;   // BVH only: index inside the model
 			f3 inv = mk(0.f, 0.f, 0.f);
 			if (HAS_MODELS) inv = mk(1.0f / dir.x, 1.0f / dir.y, 1.0f / dir.z);
 
@@ -712,13 +773,24 @@ __global__ __launch_bounds__(64, HAS_MODELS ? SRT_TRACE_WAVES_PER_SIMD_MODELS : 
 				} else if (HAS_MODELS && run.type == SRT_SHAPE_MODEL) {
 					for (uint32_t k = 0; k < cnt; k += 2) {
 						const Blk16 b = ld_blk16(d + 8 * k);
+						// the model's own box first, exactly as the reference (render.cl:316-323), then its triangles
 						if (test_aabb(b.v[0], b.v[1], b.v[2], b.v[4], b.v[5], b.v[6], org, inv, tmin)) {
-							if (COUNT_TRIS) n_tri += f2u(b.v[7]);
-							test_triangles<COUNT_TRIS>(wtris, f2u(b.v[3]), f2u(b.v[7]), org, dir, base + (int)k, tmin, best, best_tri, n_tri_u);
+							if (USE_BVH) {
+								if (f2u(b.v[7]) != 0u)
+									walk_bvh<COUNT_TRIS>(p.bvh_nodes, p.bvh_tris, f2u(b.v[3]), org, dir, base + (int)k, tmin, best, best_tri, best_j, n_tri, n_tri_u);
+							} else {
+								if (COUNT_TRIS) n_tri += f2u(b.v[7]);
+								test_triangles<COUNT_TRIS>(wtris, f2u(b.v[3]), f2u(b.v[7]), org, dir, base + (int)k, tmin, best, best_tri, n_tri_u);
+							}
 						}
 						if (k + 1 < cnt && test_aabb(b.v[8], b.v[9], b.v[10], b.v[12], b.v[13], b.v[14], org, inv, tmin)) {
-							if (COUNT_TRIS) n_tri += f2u(b.v[15]);
-							test_triangles<COUNT_TRIS>(wtris, f2u(b.v[11]), f2u(b.v[15]), org, dir, base + (int)k + 1, tmin, best, best_tri, n_tri_u);
+							if (USE_BVH) {
+								if (f2u(b.v[15]) != 0u)
+									walk_bvh<COUNT_TRIS>(p.bvh_nodes, p.bvh_tris, f2u(b.v[11]), org, dir, base + (int)k + 1, tmin, best, best_tri, best_j, n_tri, n_tri_u);
+							} else {
+								if (COUNT_TRIS) n_tri += f2u(b.v[15]);
+								test_triangles<COUNT_TRIS>(wtris, f2u(b.v[11]), f2u(b.v[15]), org, dir, base + (int)k + 1, tmin, best, best_tri, n_tri_u);
+							}
 						}
 					}
 				}
@@ -755,7 +827,9 @@ __global__ __launch_bounds__(64, HAS_MODELS ? SRT_TRACE_WAVES_PER_SIMD_MODELS : 
 					nrm = wv;
 				} else if (HAS_MODELS) {
 					const srt_model *__restrict__ m = &p.shapes[best].shape.model;
-					const float *__restrict__ w = wtris + (size_t)(first_wtri + best_tri) * SRT_WTRI_FLOATS;
+					const float *__restrict__ w = USE_BVH ? p.bvh_tris + (size_t)best_tri * SRT_BVH_TRI_FLOATS
+					                                      : wtris + (size_t)(first_wtri + best_tri) * SRT_WTRI_FLOATS;
+					if (USE_BVH) best_tri = best_j;
 					f3 v0 = mk(w[0], w[1], w[2]);
 					f3 e1 = mk(w[3], w[4], w[5]);
 					f3 e2 = mk(w[6], w[7], w[8]);
@@ -948,17 +1022,19 @@ __global__ __launch_bounds__(256) void srt_prepass_kernel(const PrepassParams p)
 	const srt_model *m = &sh->shape.model;
 	const uint32_t n = m->num_triangles;
 	const uint32_t base = p.wtri_offset[si];
-	for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += gridDim.x * blockDim.x) {
+	for (uint32_t s = blockIdx.x * blockDim.x + threadIdx.x; s < n; s += gridDim.x * blockDim.x) {
+		const uint32_t j = p.order ? p.order[base + s] : s; // BVH layout: record s of the model holds its triangle order[s]
 		const srt_triangle *t = p.triangles + (m->triangle_index + j);
 		// render.cl:325-328 then :247-248
 		f3 p0 = mat_by_vec(m->transform, ld3(t->vertices[0].pos), 1.0f);
 		f3 p1 = mat_by_vec(m->transform, ld3(t->vertices[1].pos), 1.0f);
 		f3 p2 = mat_by_vec(m->transform, ld3(t->vertices[2].pos), 1.0f);
 		f3 e1 = p1 - p0, e2 = p2 - p0;
-		float *w = p.wtris + (size_t)(base + j) * SRT_WTRI_FLOATS;
+		float *w = p.wtris + (size_t)(base + s) * (p.order ? SRT_BVH_TRI_FLOATS : SRT_WTRI_FLOATS);
 		w[0] = p0.x, w[1] = p0.y, w[2] = p0.z;
 		w[3] = e1.x, w[4] = e1.y, w[5] = e1.z;
 		w[6] = e2.x, w[7] = e2.y, w[8] = e2.z;
+		if (p.order) w[9] = dm_u2f(j), w[10] = 0.0f, w[11] = 0.0f;
 	}
 }
 
@@ -1089,14 +1165,22 @@ void srt_launch_trace(TraceParams p, bool count_triangles, int num_waves, void *
 	const bool models = p.num_models > 0;
 	auto go = [&](auto kernel) { hipLaunchKernelGGL(kernel, grid, block, need, st, p); };
 	if (!models) {
-		if (use_lds) go(srt_trace_kernel<false, true, false>);
-		else go(srt_trace_kernel<false, false, false>);
+		if (use_lds) go(srt_trace_kernel<false, true, false, false>);
+		else go(srt_trace_kernel<false, false, false, false>);
+	} else if (p.use_bvh) {
+		if (use_lds) {
+			if (count_triangles) go(srt_trace_kernel<true, true, true, true>);
+			else go(srt_trace_kernel<false, true, true, true>);
+		} else {
+			if (count_triangles) go(srt_trace_kernel<true, false, true, true>);
+			else go(srt_trace_kernel<false, false, true, true>);
+		}
 	} else if (use_lds) {
-		if (count_triangles) go(srt_trace_kernel<true, true, true>);
-		else go(srt_trace_kernel<false, true, true>);
+		if (count_triangles) go(srt_trace_kernel<true, true, true, false>);
+		else go(srt_trace_kernel<false, true, true, false>);
 	} else {
-		if (count_triangles) go(srt_trace_kernel<true, false, true>);
-		else go(srt_trace_kernel<false, false, true>);
+		if (count_triangles) go(srt_trace_kernel<true, false, true, false>);
+		else go(srt_trace_kernel<false, false, true, false>);
 	}
 }
 

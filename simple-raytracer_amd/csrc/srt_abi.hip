@@ -3,6 +3,10 @@
 // the reference's Tracer (/root/reference/src/tracer.cpp:11-116). HIP runtime only.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+#include <chrono>
+#include <cfloat>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -60,6 +64,12 @@ struct srt_tracer {
 	DevBuf<float> wtris;
 	DevBuf<uint32_t> wtri_offset;
 	DevBuf<float> sky;
+	DevBuf<BvhNode> bvh_nodes;
+	DevBuf<uint32_t> bvh_order;
+	DevBuf<float> bvh_tris;
+	int accel_mode = SRT_ACCEL_NONE; // what the next srt_update_scene builds
+	bool bvh_active = false;         // the current scene's models carry BVH roots
+	uint64_t bvh_info[4] = {0, 0, 0, 0};
 	DevBuf<unsigned long long> counters;
 	DevBuf<float> radiance;  // 3 floats per (pixel, sample) of the current batch
 	DevBuf<float> running;   // float4 per pixel, carries the ordered sum across batches
@@ -94,6 +104,179 @@ int fail(srt_tracer *t, int code, const std::string &msg) {
 	} while (0)
 
 int num_blocks(int height, int rpb) { return (height + rpb - 1) / rpb; }
+
+// ---- BVH builder (host; layout in device_types.h) --------------------
+// Top-down, binned surface-area heuristic (16 bins, all three axes), leaves of at most
+// SRT_BVH_LEAF_MAX triangles, nodes emitted in depth-first order with skip links. Runs once
+// per srt_update_scene and model instance; ~35 ms for 10^5 triangles on one host core.
+struct BvhBuilder {
+	struct Tri {
+		float lo[3], hi[3], c[3];
+		uint32_t j;
+	};
+	std::vector<Tri> tris;
+	std::vector<BvhNode> &nodes;
+	std::vector<uint32_t> &order;
+	uint32_t rec_base = 0;
+	uint32_t leaves = 0, max_depth = 0;
+
+	BvhBuilder(std::vector<BvhNode> &n, std::vector<uint32_t> &o) : nodes(n), order(o) {}
+
+	static float half_area(const float lo[3], const float hi[3]) {
+		const float dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
+		return dx * dy + dy * dz + dz * dx;
+	}
+
+	// World-space vertices as the pre-pass kernel computes them (render.cl:114-120 order); boxes
+	// are padded by 2^-12 of the model's diagonal: a hit the float Moller-Trumbore test accepts
+	// lies within rounding error of its triangle, and must still be inside every box above it.
+	void load(const srt_model &m, const srt_triangle *all) {
+		const uint32_t n = m.num_triangles;
+		tris.resize(n);
+		auto xf = [&](const srt_float3 &v, float out[3]) {
+			const srt_float4 *t = m.transform;
+			out[0] = ((t[0].x * v.x + t[1].x * v.y) + t[2].x * v.z) + t[3].x * 1.0f;
+			out[1] = ((t[0].y * v.x + t[1].y * v.y) + t[2].y * v.z) + t[3].y * 1.0f;
+			out[2] = ((t[0].z * v.x + t[1].z * v.y) + t[2].z * v.z) + t[3].z * 1.0f;
+		};
+		float mlo[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, mhi[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+		for (uint32_t j = 0; j < n; j++) {
+			const srt_triangle &tr = all[m.triangle_index + j];
+			float p[3][3];
+			for (int k = 0; k < 3; k++) xf(tr.vertices[k].pos, p[k]);
+			Tri &t = tris[j];
+			t.j = j;
+			bool finite = true;
+			for (int a = 0; a < 3; a++) {
+				// the kernel's triangle is (p0, p0 + e1, p0 + e2) with e = p_k - p0 rounded: cover both
+				const float q1 = p[0][a] + (p[1][a] - p[0][a]), q2 = p[0][a] + (p[2][a] - p[0][a]);
+				t.lo[a] = std::min(std::min(std::min(p[0][a], p[1][a]), std::min(p[2][a], q1)), q2);
+				t.hi[a] = std::max(std::max(std::max(p[0][a], p[1][a]), std::max(p[2][a], q1)), q2);
+				finite = finite && std::isfinite(t.lo[a]) && std::isfinite(t.hi[a]);
+			}
+			if (!finite) { // hostile input: a box that every ray enters, so the triangle is always tested
+				for (int a = 0; a < 3; a++) t.lo[a] = -FLT_MAX, t.hi[a] = FLT_MAX, t.c[a] = 0.0f;
+				continue;
+			}
+			for (int a = 0; a < 3; a++) {
+				t.c[a] = 0.5f * t.lo[a] + 0.5f * t.hi[a];
+				mlo[a] = std::min(mlo[a], t.lo[a]);
+				mhi[a] = std::max(mhi[a], t.hi[a]);
+			}
+		}
+		double d2 = 0.0;
+		for (int a = 0; a < 3; a++)
+			if (mhi[a] >= mlo[a]) d2 += ((double)mhi[a] - mlo[a]) * ((double)mhi[a] - mlo[a]);
+		const float pad = (float)std::min(std::sqrt(d2) * (1.0 / 4096.0), (double)FLT_MAX);
+		for (Tri &t : tris)
+			for (int a = 0; a < 3; a++) {
+				if (t.lo[a] == -FLT_MAX) continue;
+				// widen by pad plus two ulps (the slab arithmetic rounds, too); stays finite
+				t.lo[a] = std::max(-FLT_MAX, std::nextafter(std::nextafter(t.lo[a] - pad, -INFINITY), -INFINITY));
+				t.hi[a] = std::min(FLT_MAX, std::nextafter(std::nextafter(t.hi[a] + pad, INFINITY), INFINITY));
+			}
+	}
+
+	uint32_t build(uint32_t b, uint32_t e, uint32_t depth) {
+		const uint32_t self = (uint32_t)nodes.size();
+		nodes.emplace_back();
+		if (depth > max_depth) max_depth = depth;
+		float lo[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, hi[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+		float clo[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, chi[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+		for (uint32_t i = b; i < e; i++)
+			for (int a = 0; a < 3; a++) {
+				lo[a] = std::min(lo[a], tris[i].lo[a]), hi[a] = std::max(hi[a], tris[i].hi[a]);
+				clo[a] = std::min(clo[a], tris[i].c[a]), chi[a] = std::max(chi[a], tris[i].c[a]);
+			}
+		for (int a = 0; a < 3; a++) nodes[self].lo[a] = lo[a], nodes[self].hi[a] = hi[a];
+		const uint32_t n = e - b;
+		if (n <= SRT_BVH_LEAF_MAX) {
+			nodes[self].leaf = (n << 28) | (rec_base + b);
+			nodes[self].skip = (uint32_t)nodes.size();
+			leaves++;
+			return self;
+		}
+		// binned SAH over the three axes
+		constexpr int NB = 16;
+		int best_axis = -1, best_bin = 0;
+		float best_cost = INFINITY;
+		if (depth < 48) {
+			for (int a = 0; a < 3; a++) {
+				const float ext = chi[a] - clo[a];
+				if (!(ext > 0.0f) || !std::isfinite(ext)) continue;
+				const float scale = (float)NB / ext;
+				uint32_t cnt[NB] = {0};
+				float blo[NB][3], bhi[NB][3];
+				for (int k = 0; k < NB; k++)
+					for (int c = 0; c < 3; c++) blo[k][c] = FLT_MAX, bhi[k][c] = -FLT_MAX;
+				for (uint32_t i = b; i < e; i++) {
+					int k = (int)((tris[i].c[a] - clo[a]) * scale);
+					k = k < 0 ? 0 : (k >= NB ? NB - 1 : k);
+					cnt[k]++;
+					for (int c = 0; c < 3; c++) blo[k][c] = std::min(blo[k][c], tris[i].lo[c]), bhi[k][c] = std::max(bhi[k][c], tris[i].hi[c]);
+				}
+				float rarea[NB];
+				uint32_t rcnt[NB];
+				float rl[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, rh[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+				uint32_t rc = 0;
+				for (int k = NB - 1; k > 0; k--) {
+					for (int c = 0; c < 3; c++) rl[c] = std::min(rl[c], blo[k][c]), rh[c] = std::max(rh[c], bhi[k][c]);
+					rc += cnt[k];
+					rarea[k] = rc ? half_area(rl, rh) : 0.0f;
+					rcnt[k] = rc;
+				}
+				float ll[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, lh[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+				uint32_t lc = 0;
+				for (int k = 0; k < NB - 1; k++) { // split after bin k
+					for (int c = 0; c < 3; c++) ll[c] = std::min(ll[c], blo[k][c]), lh[c] = std::max(lh[c], bhi[k][c]);
+					lc += cnt[k];
+					if (lc == 0 || rcnt[k + 1] == 0) continue;
+					const float cost = half_area(ll, lh) * (float)lc + rarea[k + 1] * (float)rcnt[k + 1];
+					if (cost < best_cost) best_cost = cost, best_axis = a, best_bin = k;
+				}
+			}
+		}
+		uint32_t mid;
+		if (best_axis >= 0) {
+			const int a = best_axis;
+			const float scale = (float)NB / (chi[a] - clo[a]);
+			const float c0 = clo[a];
+			auto it = std::partition(tris.begin() + b, tris.begin() + e, [&](const Tri &t) {
+				int k = (int)((t.c[a] - c0) * scale);
+				k = k < 0 ? 0 : (k >= NB ? NB - 1 : k);
+				return k <= best_bin;
+			});
+			mid = (uint32_t)(it - tris.begin());
+		} else {
+			mid = b; // no usable split (coincident centroids, overflow, depth cap): halve by index
+		}
+		if (mid == b || mid == e) {
+			int a = 0;
+			for (int c = 1; c < 3; c++)
+				if (chi[c] - clo[c] > chi[a] - clo[a]) a = c;
+			mid = b + n / 2;
+			std::nth_element(tris.begin() + b, tris.begin() + mid, tris.begin() + e, [a](const Tri &x, const Tri &y) { return x.c[a] < y.c[a]; });
+		}
+		nodes[self].leaf = 0;
+		build(b, mid, depth + 1);
+		build(mid, e, depth + 1);
+		nodes[self].skip = (uint32_t)nodes.size();
+		return self;
+	}
+
+	// Appends the model's nodes and triangle order; returns the root's index.
+	uint32_t run(const srt_model &m, const srt_triangle *all, uint32_t first_record) {
+		rec_base = first_record;
+		load(m, all);
+		const uint32_t n0 = (uint32_t)nodes.size();
+		build(0, (uint32_t)tris.size(), 1);
+		const uint32_t n1 = (uint32_t)nodes.size();
+		for (uint32_t i = n0; i < n1; i++)
+			if (nodes[i].skip == n1) nodes[i].skip = SRT_BVH_END;
+		for (const Tri &t : tris) order.push_back(t.j);
+		return n0;
+	}
+};
 
 size_t owned_pixels(const srt_tracer *t) { return (size_t)t->owned_rows * (size_t)t->width; }
 
@@ -217,6 +400,9 @@ void srt_destroy(srt_tracer *t) {
 	t->materials.release();
 	t->wtris.release();
 	t->wtri_offset.release();
+	t->bvh_nodes.release();
+	t->bvh_order.release();
+	t->bvh_tris.release();
 	t->sky.release();
 	t->counters.release();
 	t->radiance.release();
@@ -263,6 +449,11 @@ int srt_update_scene(srt_tracer *t, const srt_shape *shapes, size_t n_shapes, co
 	std::vector<uint32_t> offs(n_shapes ? n_shapes : 1, 0u);
 	uint64_t total_wtris = 0, max_tris = 0;
 	int num_models = 0;
+	const bool use_bvh = t->accel_mode == SRT_ACCEL_BVH;
+	std::vector<BvhNode> bvh_nodes;
+	std::vector<uint32_t> bvh_order;
+	uint64_t bvh_leaves = 0, bvh_depth = 0;
+	const auto build_t0 = std::chrono::steady_clock::now();
 	auto u2f = [](uint32_t u) {
 		float f;
 		memcpy(&f, &u, 4);
@@ -306,18 +497,29 @@ int srt_update_scene(srt_tracer *t, const srt_shape *shapes, size_t n_shapes, co
 				         m.triangle_index, m.triangle_index, m.num_triangles, n_triangles);
 				return fail(t, SRT_ERR_INVALID, buf);
 			}
-			if (total_wtris + m.num_triangles > 0xffffffffull) return fail(t, SRT_ERR_INVALID, "srt_update_scene: too many world triangles");
-			data.insert(data.end(), {m.bounding_min.x, m.bounding_min.y, m.bounding_min.z, u2f((uint32_t)total_wtris), m.bounding_max.x,
-			                         m.bounding_max.y, m.bounding_max.z, u2f(m.num_triangles)});
+			if (total_wtris + m.num_triangles > (use_bvh ? 0x0fffffffull : 0xffffffffull))
+				return fail(t, SRT_ERR_INVALID, "srt_update_scene: too many world triangles");
+			uint32_t link = (uint32_t)total_wtris; // brute force: first world triangle of the model
+			if (use_bvh && m.num_triangles > 0) {
+				BvhBuilder bb(bvh_nodes, bvh_order);
+				link = bb.run(m, triangles, (uint32_t)total_wtris); // BVH: its root node
+				bvh_leaves += bb.leaves;
+				if (bb.max_depth > bvh_depth) bvh_depth = bb.max_depth;
+			}
+			data.insert(data.end(), {m.bounding_min.x, m.bounding_min.y, m.bounding_min.z, u2f(link), m.bounding_max.x, m.bounding_max.y,
+			                         m.bounding_max.z, u2f(m.num_triangles)});
 			wr.first_wtri = (uint32_t)total_wtris;
 			offs[i] = (uint32_t)total_wtris;
-			total_wtris += ((uint64_t)m.num_triangles + 3u) & ~3ull; // blocks of 4; the tail stays all-zero (never hit)
+			// brute force: blocks of 4, the tail stays all-zero (never hit); BVH: records are addressed one by one
+			total_wtris += use_bvh ? (uint64_t)m.num_triangles : (((uint64_t)m.num_triangles + 3u) & ~3ull);
 			if (m.num_triangles > max_tris) max_tris = m.num_triangles;
 			num_models++;
 		}
 	}
 	data.resize(data.size() + 32, 0.0f); // the kernel reads whole 64-byte blocks past a run's last record
 	while (data.size() % 16) data.push_back(0.0f);
+	const uint64_t build_us =
+	    (uint64_t)std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - build_t0).count();
 
 	SRT_HIP(t, hipSetDevice(t->device));
 	SRT_HIP(t, hipStreamSynchronize(t->stream)); // previous launches may still read the old scene
@@ -328,7 +530,17 @@ int srt_update_scene(srt_tracer *t, const srt_shape *shapes, size_t n_shapes, co
 	SRT_HIP(t, t->wtri_offset.reserve(n_shapes));
 	SRT_HIP(t, t->triangles.reserve(n_triangles));
 	SRT_HIP(t, t->materials.reserve(n_materials));
-	SRT_HIP(t, t->wtris.reserve((size_t)total_wtris * SRT_WTRI_FLOATS + 64)); // + slack for the loop's look-ahead pair
+	if (use_bvh) {
+		SRT_HIP(t, t->bvh_nodes.reserve(bvh_nodes.size()));
+		SRT_HIP(t, t->bvh_order.reserve(bvh_order.size()));
+		SRT_HIP(t, t->bvh_tris.reserve((size_t)total_wtris * SRT_BVH_TRI_FLOATS));
+		if (!bvh_nodes.empty())
+			SRT_HIP(t, hipMemcpyAsync(t->bvh_nodes.ptr, bvh_nodes.data(), bvh_nodes.size() * sizeof(BvhNode), hipMemcpyHostToDevice, t->stream));
+		if (!bvh_order.empty())
+			SRT_HIP(t, hipMemcpyAsync(t->bvh_order.ptr, bvh_order.data(), bvh_order.size() * sizeof(uint32_t), hipMemcpyHostToDevice, t->stream));
+	} else {
+		SRT_HIP(t, t->wtris.reserve((size_t)total_wtris * SRT_WTRI_FLOATS + 64)); // + slack for the loop's look-ahead pair
+	}
 	if (n_shapes) {
 		SRT_HIP(t, hipMemcpyAsync(t->shapes.ptr, shapes, n_shapes * sizeof(srt_shape), hipMemcpyHostToDevice, t->stream));
 		SRT_HIP(t, hipMemcpyAsync(t->winners.ptr, winners.data(), n_shapes * sizeof(WinnerRec), hipMemcpyHostToDevice, t->stream));
@@ -360,14 +572,15 @@ int srt_update_scene(srt_tracer *t, const srt_shape *shapes, size_t n_shapes, co
 		SRT_HIP(t, hipMemcpyAsync(t->materials.ptr, dev_mats.data(), n_materials * sizeof(srt_material), hipMemcpyHostToDevice, t->stream));
 
 	if (num_models > 0 && total_wtris > 0) {
-		SRT_HIP(t, hipMemsetAsync(t->wtris.ptr, 0, ((size_t)total_wtris * SRT_WTRI_FLOATS + 64) * sizeof(float), t->stream));
+		if (!use_bvh) SRT_HIP(t, hipMemsetAsync(t->wtris.ptr, 0, ((size_t)total_wtris * SRT_WTRI_FLOATS + 64) * sizeof(float), t->stream));
 		// blockIdx.y = shape index; launch in slabs of 65535 shapes
 		for (size_t base = 0; base < n_shapes; base += 65535) {
 			PrepassParams pp;
 			pp.shapes = t->shapes.ptr + base;
 			pp.triangles = t->triangles.ptr;
 			pp.wtri_offset = t->wtri_offset.ptr + base;
-			pp.wtris = t->wtris.ptr;
+			pp.wtris = use_bvh ? t->bvh_tris.ptr : t->wtris.ptr;
+			pp.order = use_bvh ? t->bvh_order.ptr : nullptr;
 			size_t cnt = n_shapes - base;
 			pp.num_shapes = (int32_t)(cnt > 65535 ? 65535 : cnt);
 			pp.num_triangles = (uint32_t)n_triangles;
@@ -380,6 +593,8 @@ int srt_update_scene(srt_tracer *t, const srt_shape *shapes, size_t n_shapes, co
 	t->sd = *scene;
 	t->sd.num_shapes = (int32_t)n_shapes; // src/tracer.cpp:94
 	t->num_models = num_models;
+	t->bvh_active = use_bvh && num_models > 0;
+	t->bvh_info[0] = bvh_nodes.size(), t->bvh_info[1] = bvh_leaves, t->bvh_info[2] = bvh_depth, t->bvh_info[3] = use_bvh ? build_us : 0;
 	t->num_runs = (int)runs.size();
 	t->num_materials = n_materials;
 	t->scene_set = true;
@@ -427,6 +642,9 @@ int srt_trace(srt_tracer *t, const srt_render_data *options) {
 	p.f_sky_h = (float)t->sky_h;
 	p.sun_focus_int = dm_pow_small_int(p.sd.sun_focus);
 	p.num_models = t->num_models;
+	p.use_bvh = t->bvh_active ? 1 : 0;
+	p.bvh_nodes = t->bvh_nodes.ptr;
+	p.bvh_tris = t->bvh_tris.ptr;
 	p.rank = t->rank;
 	p.world = t->world;
 	p.rows_per_block = t->rows_per_block;
@@ -727,6 +945,19 @@ int srt_selftest_math(srt_tracer *t, uint32_t stride, uint64_t out[12]) {
 	(void)hipFree(d);
 	if (e != hipSuccess) return fail(t, SRT_ERR_HIP, std::string("srt_selftest_math: ") + hipGetErrorString(e));
 	for (int i = 0; i < 12; i++) out[i] = h[i];
+	return SRT_OK;
+}
+
+int srt_set_acceleration(srt_tracer *t, int mode) {
+	if (!t) return SRT_ERR_INVALID;
+	if (mode != SRT_ACCEL_NONE && mode != SRT_ACCEL_BVH) return fail(t, SRT_ERR_INVALID, "srt_set_acceleration: unknown mode");
+	t->accel_mode = mode;
+	return SRT_OK;
+}
+
+int srt_acceleration_info(const srt_tracer *t, uint64_t out[4]) {
+	if (!t || !out) return SRT_ERR_INVALID;
+	for (int i = 0; i < 4; i++) out[i] = t->bvh_active ? t->bvh_info[i] : 0;
 	return SRT_OK;
 }
 

@@ -101,6 +101,9 @@ class Tracer {
 	}
 
 	// -- extras beyond the reference's interface --
+	/// SRT_ACCEL_BVH: models get a bounding-volume hierarchy at the next update_scene (the
+	/// reference's README.md:41 "future plan"); SRT_ACCEL_NONE (default) keeps the array-order scan
+	void set_acceleration(int mode) { check(srt_set_acceleration(handle, mode)); }
 	void read_canvas(std::vector<float> &rgba) {
 		rgba.resize(size_t(options.width) * size_t(options.height) * 4);
 		check(srt_read_canvas(handle, rgba.data()));

@@ -5,7 +5,7 @@
 //
 //   srt_headless [--scene spheres|meshes|empty] [--obj f.obj]... [--stl f.stl]...
 //                [--width W --height H --spp S --bounces B --frames N --time T]
-//                [--out frame.ppm] [--dump prefix] [--parse-only]
+//                [--out frame.ppm] [--dump prefix] [--parse-only] [--bvh]
 //
 // --dump prefix writes prefix.{shapes,tris,mats,rd,sd,canvas,argb}.bin (raw records).
 // --parse-only skips everything that needs a GPU (loaders + scene construction only).
@@ -54,7 +54,7 @@ int main(int argc, char **argv) {
 	std::vector<std::string> objs, stls;
 	int width = 256, height = 256, spp = 16, bounces = 10, frames = 1;
 	unsigned time_seed = 12345;
-	bool parse_only = false;
+	bool parse_only = false, bvh = false;
 	for (int i = 1; i < argc; i++) {
 		std::string a = argv[i];
 		auto next = [&]() -> const char * {
@@ -76,9 +76,10 @@ int main(int argc, char **argv) {
 		else if (a == "--out") out = next();
 		else if (a == "--dump") dump_prefix = next();
 		else if (a == "--parse-only") parse_only = true;
+		else if (a == "--bvh") bvh = true;
 		else {
 			std::cerr << "usage: srt_headless [--scene spheres|meshes|empty] [--obj f]... [--stl f]... [--width W --height H --spp S "
-			             "--bounces B --frames N --time T] [--out f.ppm] [--dump prefix] [--parse-only]\n";
+			             "--bounces B --frames N --time T] [--out f.ppm] [--dump prefix] [--parse-only] [--bvh]\n";
 			return 2;
 		}
 	}
@@ -143,6 +144,7 @@ int main(int argc, char **argv) {
 
 	// ---- tracer set-up, as src/main.cpp:114-126 ----
 	Tracer tracer(width, height);
+	if (bvh) tracer.set_acceleration(SRT_ACCEL_BVH);
 	tracer.options.num_samples = spp;
 	tracer.options.num_bounces = bounces;
 	tracer.options.show_normals = false;

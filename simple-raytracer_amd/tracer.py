@@ -27,8 +27,10 @@ ABI_SYMBOLS = [
     "srt_get_counters", "srt_set_count_triangles", "srt_reset_counters", "srt_last_kernel_ms", "srt_last_trace_kernel_ms",
     "srt_device_buffers", "srt_bind_canvas", "srt_bind_stream", "srt_set_partition",
     "srt_partition_owned_rows", "srt_partition_padded_rows", "srt_partition_global_row",
-    "srt_partition_unpermute", "srt_selftest_math", "srt_version",
+    "srt_partition_unpermute", "srt_selftest_math", "srt_version", "srt_set_acceleration", "srt_acceleration_info",
 ]
+
+ACCEL_NONE, ACCEL_BVH = 0, 1
 
 
 class Counters(C.Structure):
@@ -90,6 +92,9 @@ def load_library():
     if hasattr(lib, "srt_selftest_math"):  # absent only in older A/B builds selected through SRT_LIB
         lib.srt_selftest_math.argtypes = [vp, C.c_uint32, C.POINTER(C.c_uint64)]
     lib.srt_version.restype = C.c_char_p
+    if hasattr(lib, "srt_set_acceleration"):
+        lib.srt_set_acceleration.argtypes = [vp, i]
+        lib.srt_acceleration_info.argtypes = [vp, C.POINTER(C.c_uint64)]
     _lib = lib
     return lib
 
@@ -201,6 +206,15 @@ class Tracer:
 
     def count_triangles(self, enable=True):
         self._check(self.lib.srt_set_count_triangles(self._h, 1 if enable else 0))
+
+    def set_acceleration(self, mode):
+        """ACCEL_NONE (array-order triangle scan, the parity mode) or ACCEL_BVH; applies at the next update_scene."""
+        self._check(self.lib.srt_set_acceleration(self._h, int(mode)))
+
+    def acceleration_info(self):
+        out = (C.c_uint64 * 4)()
+        self._check(self.lib.srt_acceleration_info(self._h, out))
+        return dict(zip(("nodes", "leaves", "depth", "build_us"), (int(v) for v in out)))
 
     def selftest_math(self, stride=1):
         out = (C.c_uint64 * 12)()

@@ -1,0 +1,182 @@
+"""GPU: the optional BVH (srt_set_acceleration) against the array-order
+triangle scan and the CPU oracle. The BVH changes WHICH triangles a ray is tested against,
+never the test itself, and keeps the reference's first-in-array-order rule for hits of equal
+distance — so on well-conditioned meshes the canvas must be bit-identical to the brute-force
+one (and hence to the reference kernel's)."""
+import numpy as np
+import pytest
+
+import golden_io
+from conftest import bits_equal
+from simple_raytracer_amd import records as R, scenes as S
+from test_gpu_fuzz import random_scene
+
+pytestmark = pytest.mark.gpu
+CASES = golden_io.load_cases()
+MESH_CASES = sorted(n for n, g in CASES.items() if (g["shapes"]["type"] == 2).any())
+
+
+@pytest.fixture(scope="module")
+def T():
+    from simple_raytracer_amd import build, tracer
+    build.build_hip()
+    return tracer
+
+
+def bvh_tracer(T, g, sky, accel=1):
+    rd = g["rd"]
+    t = T.Tracer(int(rd["width"]), int(rd["height"]))
+    t.set_skybox(sky)
+    t.set_acceleration(accel)
+    t.options = rd.copy()
+    t.scene_data = g["sd"].copy()
+    t.update_scene(g["shapes"], g["tris"], g["mats"])
+    t.clear_canvas()
+    return t
+
+
+def test_there_are_mesh_goldens():
+    assert {"boxes", "mesh_smooth", "mesh_flat", "mixed"} <= set(MESH_CASES)
+
+
+@pytest.mark.parametrize("name", MESH_CASES)
+def test_golden_cases_with_bvh(name, T, sky):
+    """Every golden case that has model shapes, rendered through the BVH: canvas and ARGB bytes
+    equal the vectors generated from the reference kernel."""
+    g = CASES[name]
+    t = bvh_tracer(T, g, sky)
+    info = t.acceleration_info()
+    n_tris = int(sum(int(s["num_triangles"]) for s in g["shapes"] if s["type"] == 2))
+    assert info["nodes"] >= info["leaves"] >= (n_tris + 3) // 4 and info["depth"] >= 1
+    out = None
+    for i, tm in enumerate(g["frames"]):
+        t.options["time"] = np.uint32(tm)
+        out = t.render(i + 1)
+    assert bits_equal(t.read_canvas(), g["canvas"])
+    assert np.array_equal(out.reshape(g["argb"].shape), g["argb"])
+    t.close()
+
+
+def _both(T, sky, shapes, tris, mats, rd):
+    g = dict(shapes=shapes, tris=tris, mats=mats, rd=rd, sd=R.scene_data(len(shapes)))
+    res = []
+    for accel in (0, 1):
+        t = bvh_tracer(T, g, sky, accel)
+        t.count_triangles(True)
+        t.reset_counters()
+        t.trace()
+        res.append((t.read_canvas(), t.counters(), t.acceleration_info()))
+        t.close()
+    return res
+
+
+@pytest.mark.parametrize("scene,w,h,spp", [("mesh2", 320, 180, 4), ("mesh100k", 160, 90, 2), ("mesh100k_smooth", 96, 54, 2)])
+def test_bvh_equals_array_scan(scene, w, h, spp, T, sky):
+    """BASELINE configs[2] / configs[4] geometry at sizes the brute-force kernel finishes in a
+    second: same canvas bits, same ray / sky / path counts, far fewer triangle tests."""
+    shapes, tris, mats = {"mesh2": lambda: S.mesh_scene(2), "mesh100k": lambda: S.mesh_scene(1, 224, 224, smooth=False),
+                          "mesh100k_smooth": lambda: S.mesh_scene(1, 224, 224, smooth=True)}[scene]()
+    rd = R.render_data(w, h, spp, 10, camera_to_world=S.default_camera(), time=31337)
+    (c0, k0, i0), (c1, k1, i1) = _both(T, sky, shapes, tris, mats, rd)
+    assert i0["nodes"] == 0 and i1["nodes"] > 0
+    assert bits_equal(c1, c0)
+    for k in ("paths", "rays", "sky", "nan_pixels"):
+        assert k1[k] == k0[k], (k, k0, k1)
+    assert k1["watchdog"] == 0
+    assert 0 < k1["tri_tests"] < k0["tri_tests"] / (4 if scene == "mesh2" else 200), (k0["tri_tests"], k1["tri_tests"])
+
+
+def test_bvh_mesh100k_against_the_oracle(T, sky, oracle):
+    """The same tiny crop test_gpu_parity.py renders brute force, through the BVH, against the CPU oracle."""
+    shapes, tris, mats = S.mesh_scene(1, 224, 224, smooth=False)
+    rd = R.render_data(40, 24, 1, 10, camera_to_world=S.default_camera(), time=99)
+    g = dict(shapes=shapes, tris=tris, mats=mats, rd=rd, sd=R.scene_data(len(shapes)))
+    t = bvh_tracer(T, g, sky)
+    t.trace()
+    assert bits_equal(t.read_canvas(), oracle.render(rd, g["sd"], shapes, tris, mats, sky))
+    t.close()
+
+
+def test_equal_distance_hits_keep_array_order(T, sky):
+    """Coincident triangles: the reference keeps the FIRST of equal t (strict <, render.cl:254-256).
+    A model made of the same quad four times over, each copy with its own vertex normals, must
+    shade with copy 0's normals whatever order the BVH leaves hold them in."""
+    quad = [((-1, -1, 0), (1, -1, 0), (1, 1, 0)), ((-1, -1, 0), (1, 1, 0), (-1, 1, 0))]
+    normals = [(0, 0, 1), (0.6, 0, 0.8), (0, 0.6, 0.8), (-0.6, 0, 0.8)]
+    rng = np.random.RandomState(5)
+    recs = []
+    for n in normals:  # four coincident copies, then unrelated clutter so that the tree has several leaves
+        for a, b, c in quad:
+            recs.append(R.flat_triangle(n, a, b, c))
+    for _ in range(40):
+        p = rng.uniform(-1, 1, (3, 3)).astype(np.float32) * 0.2 + np.array([2.5, 0, 0], np.float32)
+        recs.append(R.flat_triangle((0, 0, 1), p[0], p[1], p[2]))
+    tris = np.zeros(len(recs), R.TRIANGLE)
+    for i, r in enumerate(recs):
+        tris[i] = r
+    mats = np.zeros(1, R.MATERIAL)
+    mats[0] = R.material((0.8, 0.8, 0.8))
+    shapes = np.zeros(1, R.SHAPE)
+    shapes[0] = R.model(0, tris, 0, len(tris), R.translate((0, 0, 0)))
+    rd = R.render_data(64, 48, 2, 3, camera_to_world=S.default_camera(), time=7, show_normals=True)
+    (c0, k0, _), (c1, k1, _) = _both(T, sky, shapes, tris, mats, rd)
+    assert bits_equal(c1, c0)
+    # and copy 0's normal (0, 0, 1) -> colour (0.5, 0.5, 1.0) is what the centre pixel shows
+    assert np.allclose(c1[24, 32, :3], (0.5, 0.5, 1.0))
+
+
+def test_models_without_triangles_and_instances(T, sky):
+    """An empty model, two instances of one mesh, a model-only scene; switching modes back and
+    forth on one handle."""
+    mesh = S.blob_mesh(8, 7, seed=3, smooth=True)
+    tris = R.concat(R.TRIANGLE, R.box_triangles(), mesh)
+    mats = np.zeros(2, R.MATERIAL)
+    mats[0] = R.material((0.7, 0.7, 0.9))
+    mats[1] = R.material((0.9, 0.9, 0.9), smoothness=1.0, transmittance=1.0, refraction_index=1.4)
+    shapes = np.zeros(4, R.SHAPE)
+    shapes[0] = R.model(0, tris, 12, len(mesh), R.translate((-1.2, 0, 0)))
+    shapes[1] = R.model(1, tris, 12, len(mesh), R.mat_mul(R.translate((1.2, 0.2, -0.5)), R.euler_yxz(0.7, 0.3, 0.0)))
+    shapes[2] = R.model(0, tris, 0, 0, R.translate((0, 0, 0)))
+    shapes[3] = R.box_model(0, 0, (0, -1.6, 0))
+    rd = R.render_data(96, 64, 3, 10, camera_to_world=S.default_camera(), time=2024)
+    sd = R.scene_data(len(shapes))
+    t = T.Tracer(96, 64)
+    t.set_skybox(sky)
+    t.options, t.scene_data = rd, sd
+    canv = []
+    for accel in (0, 1, 0, 1):
+        t.set_acceleration(accel)
+        t.update_scene(shapes, tris, mats)
+        t.clear_canvas()
+        t.trace()
+        canv.append(t.read_canvas())
+        assert (t.acceleration_info()["nodes"] > 0) == bool(accel)
+    t.close()
+    assert bits_equal(canv[1], canv[0]) and bits_equal(canv[2], canv[0]) and bits_equal(canv[3], canv[0])
+
+
+def test_random_scenes_with_bvh_match_oracle(sky, oracle, T):
+    """The friendly half of the differential fuzzer (test_gpu_fuzz.py) through the BVH."""
+    rng = np.random.RandomState(4711)
+    w, h = 24, 16
+    t = T.Tracer(w, h)
+    t.set_skybox(sky)
+    t.set_acceleration(1)
+    failures = []
+    for it in range(150):
+        shapes, tris, mats, cam = random_scene(rng, False)
+        rd = R.render_data(w, h, int(rng.randint(1, 5)), int(rng.choice([1, 2, 5, 10])), fov_scale=float(rng.uniform(0.3, 2.0)),
+                           camera_to_world=cam, time=int(rng.randint(1, 2**31)), show_normals=bool(rng.rand() < 0.1))
+        sd = R.scene_data(len(shapes))
+        t.options, t.scene_data = rd, sd
+        t.update_scene(shapes, tris, mats)
+        t.clear_canvas()
+        t.reset_counters()
+        t.trace()
+        got, c = t.read_canvas(), t.counters()
+        with np.errstate(all="ignore"):
+            want, oc = oracle.render(rd, sd, shapes, tris, mats, sky, counters=True, nthreads=4)
+        if not (bits_equal(got, want) and all(c[k] == oc[k] for k in ("paths", "rays", "sky", "nan_pixels")) and c["watchdog"] == 0):
+            failures.append(it)
+    t.close()
+    assert not failures, failures

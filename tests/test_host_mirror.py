@@ -86,13 +86,14 @@ def test_obj_variants_and_errors(headless, tmp_path):
 
 
 @pytest.mark.gpu
-def test_cxx_tracer_renders_like_oracle_and_writes_ppm(headless, tmp_path, oracle, sky):
+@pytest.mark.parametrize("extra", [[], ["--bvh"]], ids=["array_scan", "bvh"])
+def test_cxx_tracer_renders_like_oracle_and_writes_ppm(extra, headless, tmp_path, oracle, sky):
     obj = tmp_path / "m.obj"
     S.write_obj(obj, S.blob_mesh(10, 11, seed=3, smooth=True))
     prefix, ppm = str(tmp_path / "r"), tmp_path / "frame.ppm"
     w, h, spp, frames = 96, 64, 3, 2
     subprocess.run([headless, "--scene", "meshes", "--obj", str(obj), "--width", str(w), "--height", str(h), "--spp", str(spp),
-                    "--frames", str(frames), "--time", "4242", "--out", str(ppm), "--dump", prefix], check=True)
+                    "--frames", str(frames), "--time", "4242", "--out", str(ppm), "--dump", prefix] + extra, check=True)
     shapes, tris, mats = _load(prefix)
     rd = np.fromfile(prefix + ".rd.bin", R.RENDER_DATA)[0]
     sd = np.fromfile(prefix + ".sd.bin", R.SCENE_DATA)[0]

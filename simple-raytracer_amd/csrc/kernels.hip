@@ -197,6 +197,9 @@ __device__ __forceinline__ float log_unit(float u) {
 	float hfsq = (0.5f * f) * f;
 	float dk = (float)k;
 	float r = dk * LN2_HI + (f - (hfsq - (s * (hfsq + R) + dk * LN2_LO)));
+	// Keep the zero test a select: left alone, the compiler sinks the whole polynomial into a branch
+	// on u != 0, which also keeps the three logarithms of a bounce from being scheduled together.
+	asm volatile("" : "+v"(r));
 	return u == 0.0f ? -DM_INF_F : r;
 }
 

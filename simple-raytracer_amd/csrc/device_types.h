@@ -135,8 +135,8 @@ struct ResolveParams {
 
 void srt_launch_trace(TraceParams p, bool count_triangles, int num_waves, void *stream);
 void srt_launch_reduce(const ReduceParams &p, void *stream);
-int srt_trace_waves_per_simd(int has_models);
-int srt_sub_job_items(int has_models); /* items per LDS-staged sub-job; chunks per atomic are multiples of it */
+int srt_trace_waves_per_simd(int has_models, int use_bvh);
+int srt_sub_job_items(int has_models, int use_bvh); /* items per LDS-staged sub-job; chunks per atomic are multiples of it */
 void srt_launch_prepass(const PrepassParams &p, uint64_t total_wtris, void *stream);
 void srt_launch_resolve(const ResolveParams &p, void *stream);
 void srt_launch_selftest(unsigned long long *out12, uint32_t stride, void *stream);

@@ -568,14 +568,25 @@ __device__ __forceinline__ void flush_stage(const float *__restrict__ src, float
 #ifndef SRT_TRACE_WAVES_PER_SIMD_MODELS
 #define SRT_TRACE_WAVES_PER_SIMD_MODELS 4
 #endif
+// The BVH walk is bound by the latency of its dependent per-lane loads, not by issue, so more
+// resident waves help even at the price of ~30 spilled registers, and 64-item sub-jobs keep the
+// LDS footprint of 24 waves per CU inside 160 KB. A/B on MI355X (profiles/README.md), configs[4]
+// at full size: 4 waves x 256 items 95.7 ms, 4 x 64 90.5, 5 x 64 81.3, 6 x 64 75.7 (configs[2],
+// two 968-triangle trees: 78.5 / 85.9 / 81.1 / 80.5).
+#ifndef SRT_TRACE_WAVES_PER_SIMD_BVH
+#define SRT_TRACE_WAVES_PER_SIMD_BVH 6
+#endif
+#ifndef SRT_SUB_BVH
+#define SRT_SUB_BVH 64
+#endif
 
 // HAS_MODELS = false compiles every AABB / triangle / mesh-normal path out: scenes of
 // spheres and planes (BASELINE configs 0, 1, 3) get a leaner kernel (fewer registers, no
 // spills, smaller code); the host picks the instantiation from the scene.
 template <bool COUNT_TRIS, bool USE_LDS, bool HAS_MODELS, bool USE_BVH>
-__global__ __launch_bounds__(64, HAS_MODELS ? SRT_TRACE_WAVES_PER_SIMD_MODELS : SRT_TRACE_WAVES_PER_SIMD) void srt_trace_kernel(const TraceParams p) {
+__global__ __launch_bounds__(64, USE_BVH ? SRT_TRACE_WAVES_PER_SIMD_BVH : HAS_MODELS ? SRT_TRACE_WAVES_PER_SIMD_MODELS : SRT_TRACE_WAVES_PER_SIMD) void srt_trace_kernel(const TraceParams p) {
 	extern __shared__ float4 lds[]; // [2*n_shapes] winner records, [4*n_materials] materials, [2][SRT_SUB] staging slots
-	constexpr uint32_t SRT_SUB = HAS_MODELS ? SRT_SUB_MODELS : SRT_SUB_PLAIN;
+	constexpr uint32_t SRT_SUB = USE_BVH ? SRT_SUB_BVH : HAS_MODELS ? SRT_SUB_MODELS : SRT_SUB_PLAIN;
 	const int width = p.rd.width;
 	const int lane = threadIdx.x;
 	const int ns = p.rd.num_samples;
@@ -1150,8 +1161,10 @@ void srt_launch_selftest(unsigned long long *out, uint32_t stride, void *stream)
 // ---------------------------------------------------------------------------------
 // launch wrappers (host)
 // ---------------------------------------------------------------------------------
-int srt_trace_waves_per_simd(int has_models) { return has_models ? SRT_TRACE_WAVES_PER_SIMD_MODELS : SRT_TRACE_WAVES_PER_SIMD; }
-int srt_sub_job_items(int has_models) { return has_models ? SRT_SUB_MODELS : SRT_SUB_PLAIN; }
+int srt_trace_waves_per_simd(int has_models, int use_bvh) {
+	return !has_models ? SRT_TRACE_WAVES_PER_SIMD : use_bvh ? SRT_TRACE_WAVES_PER_SIMD_BVH : SRT_TRACE_WAVES_PER_SIMD_MODELS;
+}
+int srt_sub_job_items(int has_models, int use_bvh) { return !has_models ? SRT_SUB_PLAIN : use_bvh ? SRT_SUB_BVH : SRT_SUB_MODELS; }
 
 void srt_launch_trace(TraceParams p, bool count_triangles, int num_waves, void *stream) {
 	if (p.total_items == 0 || num_waves <= 0) return;
@@ -1163,7 +1176,7 @@ void srt_launch_trace(TraceParams p, bool count_triangles, int num_waves, void *
 	const size_t scene_lds = use_lds ? scene : 0; // both record types are multiples of 16 B
 	p.lds_bytes = (uint32_t)scene_lds;
 	p.stage_off = (uint32_t)(scene_lds / sizeof(float4));
-	const size_t need = scene_lds + 2u * (size_t)srt_sub_job_items(p.num_models > 0) * sizeof(float4) + 10u * 64u * sizeof(float);
+	const size_t need = scene_lds + 2u * (size_t)srt_sub_job_items(p.num_models > 0, p.use_bvh) * sizeof(float4) + 10u * 64u * sizeof(float);
 	hipStream_t st = (hipStream_t)stream;
 	const bool models = p.num_models > 0;
 	auto go = [&](auto kernel) { hipLaunchKernelGGL(kernel, grid, block, need, st, p); };

@@ -685,7 +685,7 @@ int srt_trace(srt_tracer *t, const srt_render_data *options) {
 	if (n_batches > 1) SRT_HIP(t, t->running.reserve(pixels * 4));
 	p.radiance = t->radiance.ptr;
 	p.queue = t->counters.ptr + SRT_CTR_QUEUE;
-	const int slots = t->num_cus * 4 * srt_trace_waves_per_simd(t->num_models > 0);
+	const int slots = t->num_cus * 4 * srt_trace_waves_per_simd(t->num_models > 0, t->bvh_active);
 
 	ReduceParams rp;
 	rp.radiance = t->radiance.ptr;
@@ -710,7 +710,7 @@ int srt_trace(srt_tracer *t, const srt_render_data *options) {
 		p.total_items = (unsigned long long)pixels * nbs;
 		// chunks per atomic: ~8 per resident wave for balance, 128..1024 items, multiple of the 128-item sub-job
 		unsigned long long job = p.total_items / ((unsigned long long)slots * 8ull);
-		const unsigned long long sub = (unsigned long long)srt_sub_job_items(t->num_models > 0);
+		const unsigned long long sub = (unsigned long long)srt_sub_job_items(t->num_models > 0, t->bvh_active);
 		job = (job / sub) * sub; // whole sub-jobs, so that every sub-job starts 16-byte aligned in the radiance buffer
 		if (job < sub) job = sub;
 		if (job > 5ull * sub) job = 5ull * sub;

@@ -61,7 +61,9 @@ struct BvhNode {
 static_assert(sizeof(BvhNode) == 32, "BvhNode 32 B");
 #define SRT_BVH_END 0xffffffffu
 #define SRT_BVH_TRI_FLOATS 12
-#define SRT_BVH_LEAF_MAX 4
+#ifndef SRT_BVH_LEAF_MAX
+#define SRT_BVH_LEAF_MAX 2 /* A/B at full size, configs[4] / configs[2]: 1: 68.5 / 75.2 ms, 2: 69.2 / 75.6, 4: 75.7 / 80.5, 8: 90.0 / 90.1 */
+#endif
 
 enum { SRT_CTR_RAYS = 0, SRT_CTR_SKY, SRT_CTR_TRI, SRT_CTR_TRI_PASS_U, SRT_CTR_NAN, SRT_CTR_PATHS, SRT_CTR_QUEUE, SRT_CTR_WATCHDOG, SRT_CTR_COUNT };
 

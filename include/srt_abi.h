@@ -89,6 +89,15 @@ int srt_set_acceleration(srt_tracer *t, int mode);
  * hierarchies (zeros without SRT_ACCEL_BVH or without models). */
 int srt_acceleration_info(const srt_tracer *t, uint64_t out[4]);
 
+/* Host-only (no device needed): the hierarchy srt_update_scene builds under SRT_ACCEL_BVH for ONE
+ * model shape, for inspection and tests. `model->type` must be SRT_SHAPE_MODEL and its triangle
+ * range must lie inside `triangles[0 .. n_triangles)`. Writes at most nodes_cap nodes and
+ * order_cap indices (order[r] = index inside the model of the triangle stored in record r;
+ * leaves refer to records) and always sets *n_nodes to the number of nodes of the hierarchy;
+ * either output may be NULL to only query that number. */
+int srt_bvh_build_host(const srt_shape *model, const srt_triangle *triangles, size_t n_triangles, srt_bvh_node *nodes_out,
+                       size_t nodes_cap, uint32_t *order_out, size_t order_cap, size_t *n_nodes);
+
 /* Tracer::clear_canvas — src/tracer.cpp:98-101. */
 int srt_clear_canvas(srt_tracer *t);
 

@@ -86,6 +86,18 @@ typedef struct srt_shape {
 	} shape;
 } srt_shape;
 
+/* One node of the optional BVH over a model's triangles (srt_set_acceleration in srt_abi.h;
+ * new, no counterpart in the reference). Nodes of a model are stored in depth-first order; a
+ * ray enters node + 1 when it hits an inner node's box and continues at `skip` otherwise
+ * (after a leaf, too), until SRT_BVH_END: no stack. */
+typedef struct srt_bvh_node {
+	float lo[3];
+	uint32_t skip; /* first node after this node's subtree, or SRT_BVH_END */
+	float hi[3];
+	uint32_t leaf; /* 0: inner node; else (count << 28) | first triangle record */
+} srt_bvh_node;
+#define SRT_BVH_END 0xffffffffu
+
 /* render.cl:79-92 / tracer.hpp:48-67 */
 typedef struct srt_render_data {
 	int32_t width, height;
@@ -145,6 +157,7 @@ SRT_STATIC_ASSERT(offsetof(srt_model, transform) == 48, "Model.transform@48");
 SRT_STATIC_ASSERT(sizeof(srt_shape) == 128, "Shape 128 B");
 SRT_STATIC_ASSERT(offsetof(srt_shape, material) == 4, "Shape.material@4");
 SRT_STATIC_ASSERT(offsetof(srt_shape, shape) == 16, "Shape.union@16");
+SRT_STATIC_ASSERT(sizeof(srt_bvh_node) == 32, "BVH node 32 B");
 SRT_STATIC_ASSERT(sizeof(srt_render_data) == 112, "RenderData 112 B");
 SRT_STATIC_ASSERT(offsetof(srt_render_data, aspect_ratio) == 16, "RenderData.aspect_ratio@16");
 SRT_STATIC_ASSERT(offsetof(srt_render_data, show_normals) == 24, "RenderData.show_normals@24");

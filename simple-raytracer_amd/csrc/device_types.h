@@ -52,14 +52,7 @@ static_assert(sizeof(WinnerRec) == 32, "WinnerRec 32 B");
  * Triangles are re-ordered so that a leaf's triangles are consecutive 48-byte records
  * {v0, e1, e2, j, 0, 0} (j = index inside the model, for the reference's first-in-array-
  * order tie rule and for the vertex normals), values as in SRT_WTRI_FLOATS above. */
-struct BvhNode {
-	float lo[3];
-	uint32_t skip;
-	float hi[3];
-	uint32_t leaf; /* 0: inner node; else (count << 28) | first record (absolute) */
-};
-static_assert(sizeof(BvhNode) == 32, "BvhNode 32 B");
-#define SRT_BVH_END 0xffffffffu
+typedef srt_bvh_node BvhNode; /* include/srt_types.h */
 #define SRT_BVH_TRI_FLOATS 12
 #ifndef SRT_BVH_LEAF_MAX
 #define SRT_BVH_LEAF_MAX 2 /* A/B at full size, configs[4] / configs[2]: 1: 68.5 / 75.2 ms, 2: 69.2 / 75.6, 4: 75.7 / 80.5, 8: 90.0 / 90.1 */

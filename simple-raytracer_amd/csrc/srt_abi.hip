@@ -955,6 +955,23 @@ int srt_set_acceleration(srt_tracer *t, int mode) {
 	return SRT_OK;
 }
 
+int srt_bvh_build_host(const srt_shape *model, const srt_triangle *triangles, size_t n_triangles, srt_bvh_node *nodes_out, size_t nodes_cap,
+                       uint32_t *order_out, size_t order_cap, size_t *n_nodes) {
+	if (!model || !n_nodes || model->type != SRT_SHAPE_MODEL || (n_triangles && !triangles)) return SRT_ERR_INVALID;
+	const srt_model &m = model->shape.model;
+	if ((uint64_t)m.triangle_index + m.num_triangles > n_triangles || m.num_triangles > 0x0fffffffu) return SRT_ERR_INVALID;
+	std::vector<BvhNode> nodes;
+	std::vector<uint32_t> order;
+	if (m.num_triangles > 0) {
+		BvhBuilder bb(nodes, order);
+		bb.run(m, triangles, 0u);
+	}
+	*n_nodes = nodes.size();
+	if (nodes_out) memcpy(nodes_out, nodes.data(), std::min(nodes.size(), nodes_cap) * sizeof(BvhNode));
+	if (order_out) memcpy(order_out, order.data(), std::min(order.size(), order_cap) * sizeof(uint32_t));
+	return SRT_OK;
+}
+
 int srt_acceleration_info(const srt_tracer *t, uint64_t out[4]) {
 	if (!t || !out) return SRT_ERR_INVALID;
 	for (int i = 0; i < 4; i++) out[i] = t->bvh_active ? t->bvh_info[i] : 0;

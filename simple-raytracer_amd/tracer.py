@@ -27,10 +27,33 @@ ABI_SYMBOLS = [
     "srt_get_counters", "srt_set_count_triangles", "srt_reset_counters", "srt_last_kernel_ms", "srt_last_trace_kernel_ms",
     "srt_device_buffers", "srt_bind_canvas", "srt_bind_stream", "srt_set_partition",
     "srt_partition_owned_rows", "srt_partition_padded_rows", "srt_partition_global_row",
-    "srt_partition_unpermute", "srt_selftest_math", "srt_version", "srt_set_acceleration", "srt_acceleration_info",
+    "srt_partition_unpermute", "srt_selftest_math", "srt_version", "srt_set_acceleration", "srt_acceleration_info", "srt_bvh_build_host",
 ]
 
 ACCEL_NONE, ACCEL_BVH = 0, 1
+
+
+BVH_NODE = np.dtype({"names": ["lo", "skip", "hi", "leaf"], "formats": [(np.float32, (3,)), np.uint32, (np.float32, (3,)), np.uint32],
+                     "offsets": [0, 12, 16, 28], "itemsize": 32})
+BVH_END = 0xFFFFFFFF
+
+
+def bvh_build_host(model_shape, triangles):
+    """(nodes, order) of the BVH the library builds for one model shape record. Host only: no GPU needed."""
+    lib = load_library()
+    shape = np.zeros(1, R.SHAPE)
+    shape[0] = model_shape
+    tris = R.as_records(triangles, R.TRIANGLE)
+    n = C.c_size_t(0)
+    rc = lib.srt_bvh_build_host(_ptr(shape), _ptr(tris), len(tris), None, 0, None, 0, C.byref(n))
+    if rc:
+        raise SrtError(f"srt_bvh_build_host failed ({rc})")
+    nodes = np.zeros(n.value, BVH_NODE)
+    order = np.zeros(int(shape[0]["num_triangles"]), np.uint32)
+    rc = lib.srt_bvh_build_host(_ptr(shape), _ptr(tris), len(tris), _ptr(nodes), len(nodes), _ptr(order), len(order), C.byref(n))
+    if rc:
+        raise SrtError(f"srt_bvh_build_host failed ({rc})")
+    return nodes, order
 
 
 class Counters(C.Structure):
@@ -95,6 +118,7 @@ def load_library():
     if hasattr(lib, "srt_set_acceleration"):
         lib.srt_set_acceleration.argtypes = [vp, i]
         lib.srt_acceleration_info.argtypes = [vp, C.POINTER(C.c_uint64)]
+        lib.srt_bvh_build_host.argtypes = [vp, vp, sz, vp, sz, vp, sz, C.POINTER(sz)]
     _lib = lib
     return lib
 

@@ -1,0 +1,162 @@
+"""CPU: the host-side BVH builder behind srt_set_acceleration, through the host-only entry
+point srt_bvh_build_host (no GPU involved). Structure invariants the stackless walk relies on,
+box containment, and a float32 re-enactment of the walk against a brute-force double-precision
+Moller-Trumbore: every triangle a ray really hits must be among the triangles the walk tests."""
+import numpy as np
+import pytest
+
+from simple_raytracer_amd import records as R, scenes as S, tracer as T
+
+END = T.BVH_END
+LEAF_MAX = 2  # SRT_BVH_LEAF_MAX (csrc/device_types.h)
+
+
+def world_vertices(shape, tris):
+    first, n = int(shape["triangle_index"]), int(shape["num_triangles"])
+    pos = tris["v"]["pos"][first:first + n].reshape(-1, 3)
+    return R.transform_points(np.asarray(shape["transform"], np.float32), pos, 1.0).reshape(n, 3, 3).astype(np.float64)
+
+
+def check_structure(nodes, order, n_tris):
+    n = len(nodes)
+    assert sorted(order.tolist()) == list(range(n_tris)), "order must be a permutation of the model's triangles"
+    skip, leaf = nodes["skip"].astype(np.int64), nodes["leaf"]
+    skip_eff = np.where(skip == END, n, skip)
+    assert (skip_eff > np.arange(n)).all(), "skip links must point forward (the walk's termination argument)"
+    covered = np.zeros(n_tris, np.int32)
+    depth_max = 0
+    stack = [(0, n, 1)]  # (node, end of its subtree, depth)
+    while stack:
+        i, end, depth = stack.pop()
+        depth_max = max(depth_max, depth)
+        assert skip_eff[i] == end, (i, skip_eff[i], end)
+        if leaf[i]:
+            cnt, first = int(leaf[i] >> 28), int(leaf[i] & 0x0FFFFFFF)
+            assert 1 <= cnt <= LEAF_MAX and first + cnt <= n_tris
+            covered[first:first + cnt] += 1
+            assert end == i + 1, "a leaf has no subtree"
+        else:
+            left = i + 1
+            right = int(skip_eff[left])
+            assert left < right < end, "an inner node has exactly two children, back to back"
+            for c in (left, right):  # children boxes inside the parent's
+                assert (nodes["lo"][c] >= nodes["lo"][i]).all() and (nodes["hi"][c] <= nodes["hi"][i]).all()
+            stack.append((left, right, depth + 1))
+            stack.append((right, end, depth + 1))
+    assert (covered == 1).all(), "every triangle record belongs to exactly one leaf"
+    return depth_max
+
+
+def check_boxes(nodes, order, wv):
+    leaf = nodes["leaf"]
+    for i in np.nonzero(leaf)[0]:
+        cnt, first = int(leaf[i] >> 28), int(leaf[i] & 0x0FFFFFFF)
+        v = wv[order[first:first + cnt]].reshape(-1, 3)
+        assert (v >= nodes["lo"][i] - 0).all() and (v <= nodes["hi"][i] + 0).all(), f"leaf {i} does not contain its triangles"
+        assert (v.min(axis=0) > nodes["lo"][i]).all() and (v.max(axis=0) < nodes["hi"][i]).all(), "boxes are padded"
+
+
+def walk(nodes, org, d):
+    """The device's walk (csrc/kernels.hip walk_bvh) with tmin = inf, in float32; returns the tested records."""
+    f = np.float32
+    org, d = org.astype(f), d.astype(f)
+    with np.errstate(all="ignore"):
+        inv = np.where(np.abs(d) >= f(2.0 ** -100), f(1) / d, np.copysign(f(2.0 ** 100), d)).astype(f)
+    tested, node, steps = [], 0, 0
+    while node != END:
+        steps += 1
+        lo, hi = nodes["lo"][node], nodes["hi"][node]
+        a1, a2 = (lo - org) * inv, (hi - org) * inv
+        tn = max(np.minimum(a1, a2).max(), f(0))
+        tf = np.maximum(a1, a2).min()
+        inside = tn <= tf * f(1.000001)
+        lf = int(nodes["leaf"][node])
+        if inside and lf:
+            tested.extend(range(lf & 0x0FFFFFFF, (lf & 0x0FFFFFFF) + (lf >> 28)))
+        node = node + 1 if (inside and not lf) else int(nodes["skip"][node])
+    return tested, steps
+
+
+def true_hits(wv, org, d):
+    v0, e1, e2 = wv[:, 0], wv[:, 1] - wv[:, 0], wv[:, 2] - wv[:, 0]
+    h = np.cross(d, e2)
+    a = (e1 * h).sum(-1)
+    with np.errstate(all="ignore"):
+        f = 1.0 / a
+        s = org - v0
+        u = f * (s * h).sum(-1)
+        q = np.cross(s, e1)
+        v = f * (q * d).sum(-1)
+        t = f * (e2 * q).sum(-1)
+        return np.nonzero((a != 0) & (u >= 0) & (u <= 1) & (v >= 0) & (u + v <= 1) & (t > 0))[0]
+
+
+MESHES = {
+    "blob968": lambda: (S.blob_mesh(22, 23, seed=1), R.mat_mul(R.translate((0.4, -0.1, 0.2)), R.mat_mul(R.euler_yxz(0.6, -0.3, 0.2), R.scale_matrix((1.0, 0.7, 1.3))))),
+    "box12": lambda: (R.box_triangles(), R.mat_mul(R.translate((1, 2, 3)), R.euler_yxz(0.3, 0.9, 0.0))),
+    "flat48": lambda: (S.blob_mesh(6, 5, seed=9, smooth=False), R.identity4()),
+    "single": lambda: (R.box_triangles()[:1], R.identity4()),
+}
+
+
+@pytest.mark.parametrize("name", sorted(MESHES))
+def test_structure_boxes_and_walk(name):
+    tris, xf = MESHES[name]()
+    tris = R.as_records(tris, R.TRIANGLE)
+    shape = R.model(0, tris, 0, len(tris), xf)
+    nodes, order = T.bvh_build_host(shape, tris)
+    assert len(nodes) >= 1 and len(order) == len(tris)
+    check_structure(nodes, order, len(tris))
+    wv = world_vertices(shape, tris)
+    check_boxes(nodes, order, wv)
+    rng = np.random.RandomState(11)
+    centre, radius = wv.reshape(-1, 3).mean(axis=0), np.abs(wv.reshape(-1, 3) - wv.reshape(-1, 3).mean(axis=0)).max() * 2.5
+    n_hits = 0
+    for k in range(300):
+        org = centre + rng.normal(size=3) * radius * (0.3 if k % 3 == 0 else 1.0)  # some origins inside the mesh
+        target = wv[rng.randint(len(wv))].mean(axis=0) + rng.normal(size=3) * 0.05
+        d = target - org
+        d /= np.linalg.norm(d)
+        if k % 10 == 0:
+            d[rng.randint(3)] = 0.0  # axis-parallel components exercise the safe inverse
+        tested, steps = walk(nodes, org, d)
+        assert steps <= len(nodes)
+        hit = true_hits(wv, org, d)
+        rec_of = np.empty(len(order), np.int64)
+        rec_of[order] = np.arange(len(order))
+        missing = set(rec_of[hit].tolist()) - set(tested)
+        assert not missing, f"ray {k}: triangles {sorted(missing)} are hit but were never tested"
+        n_hits += len(hit)
+    assert n_hits > 100
+
+
+def test_100k_triangle_mesh_builds_fast_and_well_formed():
+    import time
+    shapes, tris, _ = S.mesh_scene(1, 224, 224, smooth=False)
+    model = shapes[shapes["type"] == 2][0]
+    t0 = time.time()
+    nodes, order = T.bvh_build_host(model, tris)
+    dt = time.time() - t0
+    n = int(model["num_triangles"])
+    depth = check_structure(nodes, order, n)
+    assert n // LEAF_MAX <= int((nodes["leaf"] != 0).sum()) <= n
+    assert depth <= 64 and dt < 5.0
+
+
+def test_degenerate_inputs():
+    tris = np.zeros(8, R.TRIANGLE)
+    for i in range(8):  # eight copies of ONE triangle: coincident centroids force the index split
+        tris[i] = R.flat_triangle((0, 0, 1), (0, 0, 0), (1, 0, 0), (0, 1, 0))
+    shape = R.model(0, tris, 0, 8)
+    nodes, order = T.bvh_build_host(shape, tris)
+    check_structure(nodes, order, 8)
+    bad = tris.copy()
+    bad["v"]["pos"][3, 1] = (np.nan, 0, np.inf)  # a non-finite vertex: the triangle lands in an all-embracing box
+    nodes, order = T.bvh_build_host(R.model(0, tris, 0, 8), bad)
+    check_structure(nodes, order, 8)
+    assert np.isfinite(nodes["lo"]).all() and np.isfinite(nodes["hi"]).all()
+    empty = R.model(0, tris, 0, 0)
+    nodes, order = T.bvh_build_host(empty, tris)
+    assert len(nodes) == 0 and len(order) == 0
+    with pytest.raises(T.SrtError):
+        T.bvh_build_host(R.sphere(0, (0, 0, 0), 1.0), tris)  # not a model

@@ -24,9 +24,13 @@
 //    last improving hit survives there, so deferring is exact.
 //  * Triangles are pre-transformed to world space once per scene (srt_prepass_kernel)
 //    in the reference's operation order, removing 63 of ~115 flops per triangle test.
+//  * Model shapes optionally carry a BVH (srt_set_acceleration): a stackless per-lane walk
+//    over skip-linked nodes replaces the array scan, same triangle test, same tie rule.
 //  * No MFMA: nothing here is a contraction. Compiled with -ffp-contract=off; every
 //    float op is an IEEE add/mul/div/sqrt or a detmath.h routine so that results match
-//    the CPU oracle bit for bit (DESIGN.md "Numerics").
+//    the CPU oracle bit for bit (DESIGN.md "Numerics"). The kernel is VALU-issue bound, so
+//    instruction count is what is tuned: shared-reciprocal division, guard-free sqrt where
+//    the argument allows, no SLP vectorisation (packed fp32 ops are half rate on gfx950).
 #include <hip/hip_runtime.h>
 
 #include "detmath.h"
@@ -514,7 +518,7 @@ __device__ __forceinline__ void resolve_ring(const TraceParams &p, const float *
 } // namespace
 
 // ---------------------------------------------------------------------------------
-// Trace kernel. 64-thread workgroups = one wave = one 8x8 pixel tile.
+// Trace kernel. 64-thread workgroups = one persistent wave pulling (pixel, sample) items.
 // ---------------------------------------------------------------------------------
 // Items per LDS-staged sub-job (two 16-byte-slot buffers per wave, next to the 2.5 KB sky
 // ring). A/B on MI355X: the sphere/plane kernel runs 20 waves per CU and is fastest with
@@ -1169,7 +1173,6 @@ int srt_sub_job_items(int has_models, int use_bvh) { return !has_models ? SRT_SU
 void srt_launch_trace(TraceParams p, bool count_triangles, int num_waves, void *stream) {
 	if (p.total_items == 0 || num_waves <= 0) return;
 	dim3 grid((unsigned)num_waves), block(64);
-	// winners + materials go to LDS when small enough not to cost occupancy (20 waves/CU x 8 KB = 160 KB)
 	// winners + materials go to LDS when small enough not to cost occupancy (20 waves/CU x (3 + 4.5) KB < 160 KB)
 	const size_t scene = (size_t)p.sd.num_shapes * sizeof(WinnerRec) + (size_t)p.num_materials * sizeof(srt_material);
 	const bool use_lds = scene <= 4608;

@@ -17,8 +17,9 @@ roofline: the trace kernel is VALU-issue bound, not HBM bound (SURVEY.md §8d, H
          achieved = algorithmic lane-ops (W_ops formula of SURVEY.md §8d from the
          kernel's deterministic counters) / HIP-event kernel time; the HBM side
          (W_bytes / time against 8 TB/s) is reported next to it.
-cpu_baseline: the CPU oracle (a port; the reference's boost.compute CPU device cannot
-         exist here) on a strided row sample of the same frame, rank 0, N = 1 only.
+cpu_baseline: the reference's own render.cl compiled for x86-64 (oracle/_ref, kind
+         "reference") when that prebuilt library is present, else the CPU oracle (kind "port"),
+         on a bounded row sample of the same frame, rank 0, N = 1 only.
 """
 import argparse
 import json
@@ -71,7 +72,12 @@ def w_bytes(c, pixels, scene_bytes, sky_bytes):
 
 
 def cpu_baseline(name, sky, target_seconds=15.0):
-    """Oracle on the host cores over rows y0, y0+stride, ... of the SAME frame."""
+    """CPU rate on the host cores over a sample of the SAME frame (same scene, seeds, spp).
+    When oracle/_ref/libsrt_ref.so is present (the reference's own render.cl compiled for
+    x86-64, built where /root/reference exists and shipped prebuilt) it is what gets timed
+    (kind "reference") on a few bands of rows spread over the frame; the port runs the same
+    bands to count their rays, and the two canvases must agree bit for bit. Otherwise the
+    port alone is timed on rows y0, y0+stride, ... (kind "port")."""
     from oracle import oracle_py  # cpu_baseline leg only
     oracle_py.build()
     orc = oracle_py.Oracle("oracle")
@@ -88,6 +94,39 @@ def cpu_baseline(name, sky, target_seconds=15.0):
     _, c0 = orc.render(probe_rd, sd, shapes, tris, mats, sky, rows=(4, h), row_stride=max(1, h // 16), nthreads=threads, counters=True)
     dt0 = max(time.time() - t0, 1e-4)
     paths_per_s = c0["paths"] / dt0
+    ref = None
+    if oracle_py.ref_available():
+        try:
+            ref = oracle_py.Oracle("ref")
+        except OSError:
+            ref = None
+    if ref is not None:
+        # bands of whole rows (the reference build parallelises over rows of one contiguous range)
+        rows_wanted = int(max(8, min(h, 0.5 * target_seconds * paths_per_s / (w * spp))))
+        n_bands = 8 if h >= 64 else 1
+        band = max(1, rows_wanted // n_bands)
+        starts = [int((i + 0.5) * h / n_bands - band / 2) for i in range(n_bands)]
+        bands = [(max(0, y), min(h, max(0, y) + band)) for y in starts]
+        rays = paths = 0
+        dt_port = dt_ref = 0.0
+        same = True
+        for y0, y1 in bands:
+            t0 = time.time()
+            cp, c = orc.render(rd, sd, shapes, tris, mats, sky, rows=(y0, y1), nthreads=threads, counters=True)
+            dt_port += time.time() - t0
+            t0 = time.time()
+            cr = ref.render(rd, sd, shapes, tris, mats, sky, rows=(y0, y1), nthreads=threads)
+            dt_ref += time.time() - t0
+            rays += c["rays"]
+            paths += c["paths"]
+            a, b = cp[y0:y1, :, :3], cr[y0:y1, :, :3]  # the float3's padding lane is unspecified (the reference build carries NaNs into it)
+            same = same and bool(np.array_equal(np.isnan(a), np.isnan(b)) and np.array_equal(a.view(np.uint32)[~np.isnan(a)], b.view(np.uint32)[~np.isnan(b)]))
+        n_rows = sum(y1 - y0 for y0, y1 in bands)
+        return {
+            "value": round(rays / dt_ref / 1e6, 3), "unit": "Mray/s", "cores": threads, "kind": "reference",
+            "sample": f"oracle/_ref/libsrt_ref.so (the reference's src/render.cl compiled for x86-64, OpenMP over pixels), {len(bands)} bands of {band} rows spread over the frame ({n_rows} of {h} rows x {w} px x {spp} spp = {paths} paths, {rays} rays counted by the port on the same rows) in {dt_ref:.1f} s; the port took {dt_port:.1f} s on the same rows and its canvas is {'bit-identical' if same else 'DIFFERENT'}",
+            "mpath_per_s": round(paths / dt_ref / 1e6, 3), "port_value": round(rays / dt_port / 1e6, 3), "reference_equals_port": same,
+        }
     rows_wanted = int(max(1, min(h, target_seconds * paths_per_s / (w * spp))))
     stride = max(1, h // rows_wanted)
     y0 = stride // 2

@@ -182,7 +182,8 @@ void ref_render(const srt_render_data *data, const srt_scene_data *scene_data, f
 #else
 	(void)nthreads;
 #endif
-#pragma omp parallel for schedule(dynamic, 1)
+	// pixels, not rows, are the unit of work: a band of a few rows still fills every core
+#pragma omp parallel for collapse(2) schedule(dynamic, 16)
 	for (int y = y0; y < y1; y++) {
 		for (int x = 0; x < data->width; x++) {
 			g_gid[0] = (size_t)x;

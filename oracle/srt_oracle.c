@@ -441,10 +441,11 @@ void orc_render_strided(const srt_render_data *data, const srt_scene_data *scene
 		memset(ctr, 0, sizeof ctr);
 		if (ystride < 1) ystride = 1;
 		const int nrows = y1 > y0 ? (y1 - y0 + ystride - 1) / ystride : 0;
-#pragma omp for schedule(dynamic, 1)
+		/* pixels, not rows, are the unit of work: a sample of a few rows still fills every core */
+#pragma omp for collapse(2) schedule(dynamic, 16)
 		for (int r = 0; r < nrows; r++) {
-			const int y = y0 + r * ystride;
 			for (int x = 0; x < data->width; x++) {
+				const int y = y0 + r * ystride;
 				v3 c = render_pixel(data, &scene, x, y, ctr);
 				float *out = canvas + 4 * ((size_t)y * data->width + x);
 				out[0] += c.x;

@@ -431,9 +431,25 @@ int srt_set_skybox(srt_tracer *t, const float *rgba, int width, int height) {
 	return SRT_OK;
 }
 
+static int update_scene_impl(srt_tracer *t, const srt_shape *shapes, size_t n_shapes, const srt_triangle *triangles, size_t n_triangles,
+                             const srt_material *materials, size_t n_materials, const srt_scene_data *scene);
+
 int srt_update_scene(srt_tracer *t, const srt_shape *shapes, size_t n_shapes, const srt_triangle *triangles,
                      size_t n_triangles, const srt_material *materials, size_t n_materials,
                      const srt_scene_data *scene) {
+	// the host pass allocates (std::vector): no C++ exception may cross the C ABI
+	try {
+		return update_scene_impl(t, shapes, n_shapes, triangles, n_triangles, materials, n_materials, scene);
+	} catch (const std::bad_alloc &) {
+		if (t) t->err.clear(); // the message itself must not allocate much: a short literal fits the small-string buffer
+		return t ? fail(t, SRT_ERR_INVALID, "out of host memory") : SRT_ERR_INVALID;
+	} catch (...) {
+		return SRT_ERR_INVALID;
+	}
+}
+
+static int update_scene_impl(srt_tracer *t, const srt_shape *shapes, size_t n_shapes, const srt_triangle *triangles, size_t n_triangles,
+                             const srt_material *materials, size_t n_materials, const srt_scene_data *scene) {
 	if (!t) return SRT_ERR_INVALID;
 	if (!scene) return fail(t, SRT_ERR_INVALID, "srt_update_scene: scene is NULL");
 	if ((n_shapes && !shapes) || (n_triangles && !triangles) || (n_materials && !materials))
@@ -960,15 +976,19 @@ int srt_bvh_build_host(const srt_shape *model, const srt_triangle *triangles, si
 	if (!model || !n_nodes || model->type != SRT_SHAPE_MODEL || (n_triangles && !triangles)) return SRT_ERR_INVALID;
 	const srt_model &m = model->shape.model;
 	if ((uint64_t)m.triangle_index + m.num_triangles > n_triangles || m.num_triangles > 0x0fffffffu) return SRT_ERR_INVALID;
-	std::vector<BvhNode> nodes;
-	std::vector<uint32_t> order;
-	if (m.num_triangles > 0) {
-		BvhBuilder bb(nodes, order);
-		bb.run(m, triangles, 0u);
+	try {
+		std::vector<BvhNode> nodes;
+		std::vector<uint32_t> order;
+		if (m.num_triangles > 0) {
+			BvhBuilder bb(nodes, order);
+			bb.run(m, triangles, 0u);
+		}
+		*n_nodes = nodes.size();
+		if (nodes_out) memcpy(nodes_out, nodes.data(), std::min(nodes.size(), nodes_cap) * sizeof(BvhNode));
+		if (order_out) memcpy(order_out, order.data(), std::min(order.size(), order_cap) * sizeof(uint32_t));
+	} catch (...) { // std::bad_alloc: no C++ exception may cross the C ABI
+		return SRT_ERR_INVALID;
 	}
-	*n_nodes = nodes.size();
-	if (nodes_out) memcpy(nodes_out, nodes.data(), std::min(nodes.size(), nodes_cap) * sizeof(BvhNode));
-	if (order_out) memcpy(order_out, order.data(), std::min(order.size(), order_cap) * sizeof(uint32_t));
 	return SRT_OK;
 }
 

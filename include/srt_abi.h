@@ -186,7 +186,9 @@ int srt_partition_unpermute(const void *gathered, void *image, int height, int w
  * result bit patterns of detmath's log, cos, sqrt, atan2pi, pow on the device, to be
  * compared with the same sums from the host build of csrc/detmath.h; out[8..10] = mismatch
  * counts of the kernel's shared-reciprocal division, its normalize and its unguarded
- * Box-Muller square root against IEEE `/` and sqrt (must be 0); out[11] = 0. */
+ * Box-Muller square root against IEEE `/` and sqrt (must be 0); out[11] = mismatch count of the
+ * RNG-scaling shortcuts (log of the raw count, theta from the raw count) against the plain forms
+ * (must be 0). */
 int srt_selftest_math(srt_tracer *t, uint32_t stride, uint64_t out[12]);
 
 /* Library / build identification, e.g. "srt-hip gfx950 parity fp-contract=off". */

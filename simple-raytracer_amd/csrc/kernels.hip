@@ -168,21 +168,30 @@ __device__ __forceinline__ f3 mat_by_vec(const srt_float4 *m, f3 v, float w) {
 __device__ __forceinline__ f3 reflect3(f3 v, f3 n) { return v - n * (2.0f * dot3(v, n)); }
 
 // PCG-RXS-M-XS-32 (render.cl:143-148); (float)UINT_MAX == 2^32
-__device__ __forceinline__ float random_float(uint32_t &seed) {
+// random_count = (float)r, random_float = random_count / 2^32. The scaling by 2^-32 is exact and
+// never underflows (the smallest non-zero count is 1), so it commutes with any later rounding:
+// users that can absorb it into a constant or an exponent take the count and save the multiply.
+__device__ __forceinline__ float random_count(uint32_t &seed) {
 	seed = seed * 747796405u + 2891336453u;
 	uint32_t r = ((seed >> ((seed >> 28) + 4u)) ^ seed) * 277803737u;
 	r = (r >> 22) ^ r;
-	return (float)r * 2.3283064365386963e-10f; // exact: division by 2^32
+	return (float)r;
+}
+__device__ __forceinline__ float random_float(uint32_t &seed) {
+	return random_count(seed) * 2.3283064365386963e-10f; // exact: division by 2^32
 }
 
 // dm_logf restricted to what random_float can return: 0 or a normal float in
 // [2^-32, 1]. Same operations on that domain as detmath.h's dm_logf (whose negative /
 // subnormal / inf / NaN handling can never trigger here), so the same bits.
-__device__ __forceinline__ float log_unit(float u) {
+// EXP_BIAS = 127 for u itself; 159 when handed the count c = u * 2^32 instead (same mantissa,
+// exponent 32 higher, zero stays zero).
+template <int EXP_BIAS>
+__device__ __forceinline__ float log_unit_biased(float u) {
 	const float LN2_HI = 6.93138123e-01f, LN2_LO = 9.05800061e-06f;
 	const float L0 = 6.66666687e-01f, L1 = 4.00001287e-01f, L2 = 2.85499692e-01f, L3 = 2.33534276e-01f;
 	uint32_t ix = dm_f2u(u);
-	int k = (int)(ix >> 23) - 127;
+	int k = (int)(ix >> 23) - EXP_BIAS;
 	ix &= 0x007fffffu;
 	uint32_t i = (ix + 0x4afb20u) & 0x00800000u;
 	float x = dm_u2f(ix | (i ^ 0x3f800000u));
@@ -206,6 +215,8 @@ __device__ __forceinline__ float log_unit(float u) {
 	asm volatile("" : "+v"(r));
 	return u == 0.0f ? -DM_INF_F : r;
 }
+__device__ __forceinline__ float log_unit(float u) { return log_unit_biased<127>(u); }
+__device__ __forceinline__ float log_count(float c) { return log_unit_biased<159>(c); } // log(c / 2^32)
 
 // dm_cosf restricted to finite x in [0, 8): detmath.h's range / NaN guard dropped.
 __device__ __forceinline__ float cos_2pi(float x) {
@@ -229,9 +240,14 @@ __device__ __forceinline__ float cos_2pi(float x) {
 
 // Box-Muller, theta drawn first (render.cl:150-154)
 __device__ __forceinline__ float random_normal(uint32_t &seed) {
-	float theta = 6.28318548f * random_float(seed);
+#ifndef SRT_NO_COUNT_FOLD
+	float theta = (6.28318548f * 2.3283064365386963e-10f) * random_count(seed); // = 6.28318548f * random_float, bit for bit
 	// -2 log u is -0, +inf or in [1.19e-7, 44.4] for every u random_float can return: no small-argument guard
+	float rho = sqrt_core(-2.0f * log_count(random_count(seed)));
+#else
+	float theta = 6.28318548f * random_float(seed);
 	float rho = sqrt_core(-2.0f * log_unit(random_float(seed)));
+#endif
 	return rho * cos_2pi(theta);
 }
 
@@ -1095,6 +1111,7 @@ __global__ __launch_bounds__(256) void srt_resolve_kernel(const ResolveParams p)
 //          (a, b: random mantissas and signs, exponents straddling the fast paths' guards,
 //           zero components mixed in)
 //   out[10] sqrt_core(-2 log_unit(u)) != IEEE sqrt, the one call site without a guard
+//   out[11] the 2^-32 scaling folded away: log_count(r) != log_unit(u), or K' * r != 6.28318548f * u
 // ---------------------------------------------------------------------------------
 namespace {
 __device__ __forceinline__ bool same_float(float a, float b) { return (a != a && b != b) || dm_f2u(a) == dm_f2u(b); }
@@ -1114,7 +1131,7 @@ __device__ __forceinline__ bool same_f3(f3 a, f3 b) { return same_float(a.x, b.x
 
 __global__ __launch_bounds__(256) void srt_selftest_kernel(unsigned long long *out, uint32_t stride) {
 	unsigned long long bad_sqrt = 0, bad_log = 0, bad_cos = 0, s_log = 0, s_cos = 0, s_sqrt = 0, s_atan = 0, s_pow = 0;
-	unsigned long long bad_div = 0, bad_norm = 0, bad_rn = 0;
+	unsigned long long bad_div = 0, bad_norm = 0, bad_rn = 0, bad_fold = 0;
 	const unsigned long long total = (0x100000000ull + stride - 1) / stride;
 	for (unsigned long long i = blockIdx.x * (unsigned long long)blockDim.x + threadIdx.x; i < total;
 	     i += (unsigned long long)gridDim.x * blockDim.x) {
@@ -1132,6 +1149,8 @@ __global__ __launch_bounds__(256) void srt_selftest_kernel(unsigned long long *o
 		s_sqrt += canon_bits(dm_sqrtf(u));
 		s_atan += canon_bits(dm_atan2pif(u - 0.5f, 0.37f - u));
 		s_pow += canon_bits(dm_powf(u, 25.0f));
+		const float cnt = (float)r;
+		bad_fold += (same_float(log_count(cnt), log_unit(u)) && same_float((6.28318548f * 2.3283064365386963e-10f) * cnt, th)) ? 0 : 1;
 		const float arg = -2.0f * lg;
 		bad_rn += same_float(sqrt_core(arg), __builtin_sqrtf(arg)) ? 0 : 1;
 		// guards: numerators 2^-60 .. 2^50, denominator 2^-40 .. 2^40, squared length 2^-80 .. 2^80
@@ -1156,6 +1175,7 @@ __global__ __launch_bounds__(256) void srt_selftest_kernel(unsigned long long *o
 	atomicAdd(&out[8], bad_div);
 	atomicAdd(&out[9], bad_norm);
 	atomicAdd(&out[10], bad_rn);
+	atomicAdd(&out[11], bad_fold);
 }
 
 void srt_launch_selftest(unsigned long long *out, uint32_t stride, void *stream) {

@@ -294,7 +294,7 @@ def main():
         achieved = ops / kt / 1e12 / world  # per-GPU rate: each GPU ran 1/world of the ops in kt
         traffic = None
         tf = ROOT / "profiles" / "traffic.json"
-        if tf.exists():
+        if tf.exists() and world == 1:  # measured for the whole frame on one GPU
             try:
                 traffic = json.loads(tf.read_text()).get(args.workload if not args.spp else "", {}).get("hbm_bytes_per_launch")
             except Exception:

@@ -925,7 +925,9 @@ __global__ __launch_bounds__(64, USE_BVH ? SRT_TRACE_WAVES_PER_SIMD_BVH : HAS_MO
 							float mu = front ? m1.z : ior;
 							float r0 = front ? m1.w : mc.w;
 							float cos_theta = dm_min(1.0f, dot3(in_dir, neg(nrm)));
-							float sin_theta = sqrt_ieee(1.0f - cos_theta * cos_theta);
+							// 1 - x with x >= 0 is 0, or at least 2^-25 in magnitude (x < 0.5: above 0.5; x >= 0.5: a multiple
+							// of 2^-24), or inf / NaN: never inside sqrt_ieee's guarded interval (0, 2^-96) -- here and below
+							float sin_theta = sqrt_core(1.0f - cos_theta * cos_theta);
 							bool reflected = mu * sin_theta > 1.0f;
 							if (!reflected) reflected = schlick(r0, cos_theta) > random_float(seed); // short-circuit ||
 							if (reflected) {
@@ -933,7 +935,7 @@ __global__ __launch_bounds__(64, USE_BVH ? SRT_TRACE_WAVES_PER_SIMD_BVH : HAS_MO
 							} else {
 								f3 out_perp = (in_dir + nrm * cos_theta) * mu;
 								float lsq = (out_perp.x * out_perp.x + out_perp.y * out_perp.y) + out_perp.z * out_perp.z;
-								f3 out_parallel = nrm * (-sqrt_ieee(dm_fabs(1.0f - lsq)));
+								f3 out_parallel = nrm * (-sqrt_core(dm_fabs(1.0f - lsq)));
 								dir = out_perp + out_parallel;
 								mask = mask * mcolor;
 							}

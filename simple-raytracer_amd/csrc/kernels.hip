@@ -638,7 +638,13 @@ __global__ __launch_bounds__(64, USE_BVH ? SRT_TRACE_WAVES_PER_SIMD_BVH : HAS_MO
 	// A sub-job's radiances are staged in LDS (two buffers, ping-pong) and written to HBM in
 	// one fully coalesced burst of whole 64-byte lines when its last path has finished,
 	// instead of 12 scattered bytes per lane (which made the L2 fetch every line first).
-	unsigned long long chunk_cur = 0, chunk_end = 0;                 // wave-uniform
+	// The first chunk of a wave is its own (chunk number = workgroup number): thousands of waves starting
+	// together would otherwise queue up on one atomic (0.37 -> 0.30 ms for an interactive-size frame).
+	// The shared cursor hands out the chunks behind those.
+	const unsigned long long own_chunks_end = (unsigned long long)gridDim.x * p.job_items;
+	unsigned long long chunk_cur = (unsigned long long)blockIdx.x * p.job_items, chunk_end = chunk_cur + p.job_items; // wave-uniform
+	if (chunk_end > p.total_items) chunk_end = p.total_items;
+	if (chunk_cur >= p.total_items) chunk_cur = chunk_end = 0;
 	unsigned long long base0 = 0, base1 = 0;                         // first item of the sub-job in buffer 0 / 1
 	uint32_t total0 = 0, total1 = 0;                                 // items of the sub-job staged in each buffer (0 = free)
 	uint32_t issued = 0, cur = 0;                                    // issue cursor of the current buffer `cur`
@@ -690,7 +696,7 @@ __global__ __launch_bounds__(64, USE_BVH ? SRT_TRACE_WAVES_PER_SIMD_BVH : HAS_MO
 					if (chunk_cur == chunk_end) {
 						unsigned long long start = 0;
 						if (lane == 0) start = atomicAdd(p.queue, (unsigned long long)p.job_items);
-						start = (unsigned long long)__shfl((long long)start, 0);
+						start = (unsigned long long)__shfl((long long)start, 0) + own_chunks_end;
 						if (start >= total_items) {
 							queue_dry = true;
 						} else {

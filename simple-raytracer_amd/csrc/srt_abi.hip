@@ -729,13 +729,20 @@ int srt_trace(srt_tracer *t, const srt_render_data *options) {
 		// (an interactive 960x540 frame at 2 spp is 200 items per wave) gets ONE chunk per wave instead:
 		// measured 0.39 -> 0.35 ms against two rounds of single sub-jobs.
 		const unsigned long long sub = (unsigned long long)srt_sub_job_items(t->num_models > 0, t->bvh_active);
-		unsigned long long job = (p.total_items / ((unsigned long long)slots * 8ull) / sub) * sub;
-		if (job < sub) job = ((p.total_items + (unsigned long long)slots - 1ull) / (unsigned long long)slots + sub - 1ull) / sub * sub;
+		// A small dispatch ends in the tail of its longest paths, during which every resident wave still
+		// issues whole iterations for a few live lanes: fewer, faster waves win there (960x540x2spp:
+		// 2 / 3 / 4 / 5 waves per SIMD = 0.28 / 0.27 / 0.30 / 0.31 ms). At least ~320 items per wave, and
+		// never fewer than 2 waves per SIMD.
+		unsigned long long slots_b = p.total_items / 320ull;
+		if (slots_b < (unsigned long long)t->num_cus * 8ull) slots_b = (unsigned long long)t->num_cus * 8ull;
+		if (slots_b > (unsigned long long)slots) slots_b = (unsigned long long)slots;
+		unsigned long long job = (p.total_items / (slots_b * 8ull) / sub) * sub;
+		if (job < sub) job = ((p.total_items + slots_b - 1ull) / slots_b + sub - 1ull) / sub * sub;
 		if (job < sub) job = sub;
 		if (job > 5ull * sub) job = 5ull * sub;
 		p.job_items = (uint32_t)job;
 		const unsigned long long waves_needed = (p.total_items + 63ull) / 64ull;
-		const int num_waves = (int)(waves_needed < (unsigned long long)slots ? waves_needed : (unsigned long long)slots);
+		const int num_waves = (int)(waves_needed < slots_b ? waves_needed : slots_b);
 		SRT_HIP(t, hipMemsetAsync(p.queue, 0, sizeof(unsigned long long), t->stream));
 		if (b == 0) SRT_HIP(t, hipEventRecord(t->ev_k0, t->stream));
 		srt_launch_trace(p, t->count_tris, num_waves, t->stream);

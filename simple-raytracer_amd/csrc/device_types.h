@@ -58,6 +58,13 @@ typedef srt_bvh_node BvhNode; /* include/srt_types.h */
 #define SRT_BVH_LEAF_MAX 2 /* A/B at full size, configs[4] / configs[2]: 1: 68.5 / 75.2 ms, 2: 69.2 / 75.6, 4: 75.7 / 80.5, 8: 90.0 / 90.1 */
 #endif
 
+/* Work counters are kept per persistent wave (workgroup index), one 64-byte line each, and
+ * summed on the host when asked for: thousands of waves ending together on three shared atomics
+ * cost a small dispatch 100 us (profiles/README.md). Launches of a handle are stream-ordered and a
+ * launch has one wave per index, so a plain read-modify-write is enough. */
+#define SRT_WAVE_CTR_STRIDE 8 /* unsigned long long per wave: rays, sky, paths, tri, tri_pass_u, 3 spare */
+#define SRT_WAVE_CTR_SLOTS 8192 /* >= CUs * 4 SIMDs * 8 waves */
+
 enum { SRT_CTR_RAYS = 0, SRT_CTR_SKY, SRT_CTR_TRI, SRT_CTR_TRI_PASS_U, SRT_CTR_NAN, SRT_CTR_PATHS, SRT_CTR_QUEUE, SRT_CTR_WATCHDOG, SRT_CTR_COUNT };
 
 struct TraceParams {
@@ -77,7 +84,8 @@ struct TraceParams {
 	const float *sky; /* RGBA32F */
 	float *canvas;    /* float4 per owned pixel, packed rows (written by the reduce kernel) */
 	float *radiance;  /* 3 floats per work-item of the current batch: [pixel][sample in batch] */
-	unsigned long long *counters;
+	unsigned long long *counters;      /* SRT_CTR_*: only the watchdog counter is touched by the trace kernel */
+	unsigned long long *wave_counters; /* [SRT_WAVE_CTR_SLOTS][SRT_WAVE_CTR_STRIDE] */
 	unsigned long long *queue;       /* global work cursor (items), zeroed before every launch */
 	unsigned long long total_items;  /* owned pixels * batch_samples */
 	uint32_t batch_samples;          /* samples per pixel in this batch */

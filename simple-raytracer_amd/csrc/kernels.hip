@@ -694,9 +694,11 @@ __global__ __launch_bounds__(64, USE_BVH ? SRT_TRACE_WAVES_PER_SIMD_BVH : HAS_MO
 				}
 				if (other_free) {
 					if (chunk_cur == chunk_end) {
-						unsigned long long start = 0;
-						if (lane == 0) start = atomicAdd(p.queue, (unsigned long long)p.job_items);
-						start = (unsigned long long)__shfl((long long)start, 0) + own_chunks_end;
+						unsigned long long start = total_items;
+						if (own_chunks_end < total_items) { // else every chunk is some wave's first: nothing to ask the cursor for
+							if (lane == 0) start = atomicAdd(p.queue, (unsigned long long)p.job_items);
+							start = (unsigned long long)__shfl((long long)start, 0) + own_chunks_end;
+						}
 						if (start >= total_items) {
 							queue_dry = true;
 						} else {
@@ -989,8 +991,8 @@ __global__ __launch_bounds__(64, USE_BVH ? SRT_TRACE_WAVES_PER_SIMD_BVH : HAS_MO
 	if (total0 != 0u) flush_stage(reinterpret_cast<const float *>(stage), p.radiance + base0 * 3ull, total0, lane);
 	if (total1 != 0u) flush_stage(reinterpret_cast<const float *>(stage + SRT_SUB), p.radiance + base1 * 3ull, total1, lane);
 
-	// one atomic per wave and counter
-	unsigned long long r = w_rays, k = w_sky, np = w_paths, t3 = n_tri, t4 = n_tri_u;
+	// per-wave counters: this wave's own 64-byte line, no atomics (device_types.h)
+	unsigned long long t3 = n_tri, t4 = n_tri_u;
 	if (COUNT_TRIS) {
 		for (int off = 32; off > 0; off >>= 1) {
 			t3 += __shfl_down(t3, off);
@@ -998,12 +1000,13 @@ __global__ __launch_bounds__(64, USE_BVH ? SRT_TRACE_WAVES_PER_SIMD_BVH : HAS_MO
 		}
 	}
 	if (lane == 0) {
-		atomicAdd(&p.counters[SRT_CTR_RAYS], r);
-		atomicAdd(&p.counters[SRT_CTR_SKY], k);
-		atomicAdd(&p.counters[SRT_CTR_PATHS], np);
+		unsigned long long *__restrict__ w = p.wave_counters + (size_t)blockIdx.x * SRT_WAVE_CTR_STRIDE;
+		w[0] += w_rays;
+		w[1] += w_sky;
+		w[2] += w_paths;
 		if (COUNT_TRIS) {
-			atomicAdd(&p.counters[SRT_CTR_TRI], t3);
-			atomicAdd(&p.counters[SRT_CTR_TRI_PASS_U], t4);
+			w[3] += t3;
+			w[4] += t4;
 		}
 	}
 }

@@ -71,6 +71,7 @@ struct srt_tracer {
 	bool bvh_active = false;         // the current scene's models carry BVH roots
 	uint64_t bvh_info[4] = {0, 0, 0, 0};
 	DevBuf<unsigned long long> counters;
+	DevBuf<unsigned long long> wave_counters; // per persistent wave, summed in srt_get_counters
 	DevBuf<float> radiance;  // 3 floats per (pixel, sample) of the current batch
 	DevBuf<float> running;   // float4 per pixel, carries the ordered sum across batches
 	size_t radiance_budget = 0; // bytes; 0 = pick from free HBM at first use
@@ -369,6 +370,7 @@ int srt_create(int width, int height, int device_index, srt_tracer **out) {
 	t->canvas_bytes = px * 16;
 	if ((e = t->argb.reserve(px * 4)) != hipSuccess) return bail("argb alloc", e);
 	if ((e = t->counters.reserve(SRT_CTR_COUNT)) != hipSuccess) return bail("counter alloc", e);
+	if ((e = t->wave_counters.reserve((size_t)SRT_WAVE_CTR_SLOTS * SRT_WAVE_CTR_STRIDE)) != hipSuccess) return bail("counter alloc", e);
 	if ((e = t->shapes.reserve(1)) != hipSuccess || (e = t->runs.reserve(1)) != hipSuccess ||
 	    (e = t->run_data.reserve(32)) != hipSuccess || (e = t->winners.reserve(1)) != hipSuccess ||
 	    (e = t->triangles.reserve(1)) != hipSuccess || (e = t->materials.reserve(1)) != hipSuccess ||
@@ -379,6 +381,8 @@ int srt_create(int width, int height, int device_index, srt_tracer **out) {
 	    (e = hipEventCreate(&t->ev_k0)) != hipSuccess || (e = hipEventCreate(&t->ev_k1)) != hipSuccess)
 		return bail("hipEventCreate", e);
 	if ((e = hipMemsetAsync(t->canvas, 0, t->canvas_bytes, t->stream)) != hipSuccess) return bail("canvas clear", e);
+	if ((e = hipMemsetAsync(t->wave_counters.ptr, 0, (size_t)SRT_WAVE_CTR_SLOTS * SRT_WAVE_CTR_STRIDE * sizeof(unsigned long long), t->stream)) != hipSuccess)
+		return bail("counter clear", e);
 	if ((e = hipMemsetAsync(t->counters.ptr, 0, SRT_CTR_COUNT * sizeof(unsigned long long), t->stream)) != hipSuccess)
 		return bail("counter clear", e);
 	if ((e = hipStreamSynchronize(t->stream)) != hipSuccess) return bail("sync", e);
@@ -405,6 +409,7 @@ void srt_destroy(srt_tracer *t) {
 	t->bvh_tris.release();
 	t->sky.release();
 	t->counters.release();
+	t->wave_counters.release();
 	t->radiance.release();
 	t->running.release();
 	if (t->ev_t0) (void)hipEventDestroy(t->ev_t0);
@@ -650,6 +655,7 @@ int srt_trace(srt_tracer *t, const srt_render_data *options) {
 	p.sky = t->sky.ptr;
 	p.canvas = t->canvas;
 	p.counters = t->counters.ptr;
+	p.wave_counters = t->wave_counters.ptr;
 	p.sky_w = t->sky_w;
 	p.sky_h = t->sky_h;
 	p.f_width = (float)options->width;
@@ -701,7 +707,8 @@ int srt_trace(srt_tracer *t, const srt_render_data *options) {
 	if (n_batches > 1) SRT_HIP(t, t->running.reserve(pixels * 4));
 	p.radiance = t->radiance.ptr;
 	p.queue = t->counters.ptr + SRT_CTR_QUEUE;
-	const int slots = t->num_cus * 4 * srt_trace_waves_per_simd(t->num_models > 0, t->bvh_active);
+	int slots = t->num_cus * 4 * srt_trace_waves_per_simd(t->num_models > 0, t->bvh_active);
+	if (slots > SRT_WAVE_CTR_SLOTS) slots = SRT_WAVE_CTR_SLOTS; // one counter line per persistent wave
 
 	ReduceParams rp;
 	rp.radiance = t->radiance.ptr;
@@ -848,13 +855,23 @@ int srt_get_counters(srt_tracer *t, srt_counters *out) {
 	if (!out) return fail(t, SRT_ERR_INVALID, "srt_get_counters: NULL");
 	SRT_HIP(t, hipSetDevice(t->device));
 	unsigned long long h[SRT_CTR_COUNT];
+	std::vector<unsigned long long> w;
+	try {
+		w.resize((size_t)SRT_WAVE_CTR_SLOTS * SRT_WAVE_CTR_STRIDE);
+	} catch (...) {
+		return fail(t, SRT_ERR_INVALID, "out of host memory");
+	}
 	SRT_HIP(t, hipMemcpyAsync(h, t->counters.ptr, sizeof h, hipMemcpyDeviceToHost, t->stream));
+	SRT_HIP(t, hipMemcpyAsync(w.data(), t->wave_counters.ptr, w.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, t->stream));
 	SRT_HIP(t, hipStreamSynchronize(t->stream));
-	out->paths = h[SRT_CTR_PATHS];
-	out->rays = h[SRT_CTR_RAYS];
-	out->sky = h[SRT_CTR_SKY];
-	out->tri_tests = h[SRT_CTR_TRI];
-	out->tri_pass_u = h[SRT_CTR_TRI_PASS_U];
+	unsigned long long sum[5] = {0, 0, 0, 0, 0};
+	for (size_t i = 0; i < (size_t)SRT_WAVE_CTR_SLOTS; i++)
+		for (int k = 0; k < 5; k++) sum[k] += w[i * SRT_WAVE_CTR_STRIDE + k];
+	out->rays = sum[0];
+	out->sky = sum[1];
+	out->paths = sum[2];
+	out->tri_tests = sum[3];
+	out->tri_pass_u = sum[4];
 	out->nan_pixels = h[SRT_CTR_NAN];
 	out->watchdog = h[SRT_CTR_WATCHDOG];
 	return SRT_OK;
@@ -864,6 +881,7 @@ int srt_reset_counters(srt_tracer *t) {
 	if (!t) return SRT_ERR_INVALID;
 	SRT_HIP(t, hipSetDevice(t->device));
 	SRT_HIP(t, hipMemsetAsync(t->counters.ptr, 0, SRT_CTR_COUNT * sizeof(unsigned long long), t->stream));
+	SRT_HIP(t, hipMemsetAsync(t->wave_counters.ptr, 0, (size_t)SRT_WAVE_CTR_SLOTS * SRT_WAVE_CTR_STRIDE * sizeof(unsigned long long), t->stream));
 	return SRT_OK;
 }
 

@@ -69,7 +69,8 @@ struct srt_tracer {
 	DevBuf<float> bvh_tris;
 	int accel_mode = SRT_ACCEL_NONE; // what the next srt_update_scene builds
 	bool bvh_active = false;         // the current scene's models carry BVH roots
-	uint64_t bvh_info[4] = {0, 0, 0, 0};
+	uint64_t bvh_info[6] = {0, 0, 0, 0, 0, 0};
+	struct BvhCache *bvh_cache = nullptr; // hierarchies of the previous srt_update_scene (see BvhCacheEntry)
 	DevBuf<unsigned long long> counters;
 	DevBuf<unsigned long long> wave_counters; // per persistent wave, summed in srt_get_counters
 	DevBuf<float> radiance;  // 3 floats per (pixel, sample) of the current batch
@@ -279,6 +280,23 @@ struct BvhBuilder {
 	}
 };
 
+// One model instance's hierarchy with indices relative to its own first node / first record, kept
+// between srt_update_scene calls together with what it was built from: an edit that leaves a model's
+// triangles and transform alone (camera, materials, sun, OTHER shapes) re-uses it instead of paying
+// the build again (10^5 triangles: 37 ms -> 1.5 ms for the comparison).
+struct BvhCacheEntry {
+	uint32_t count = 0;
+	srt_float4 transform[4];
+	std::vector<srt_triangle> tris;
+	std::vector<BvhNode> nodes;
+	std::vector<uint32_t> order;
+	uint32_t leaves = 0, depth = 0;
+	bool matches(const srt_model &m, const srt_triangle *all) const {
+		return m.num_triangles == count && memcmp(transform, m.transform, sizeof transform) == 0 &&
+		       memcmp(tris.data(), all + m.triangle_index, (size_t)count * sizeof(srt_triangle)) == 0;
+	}
+};
+
 size_t owned_pixels(const srt_tracer *t) { return (size_t)t->owned_rows * (size_t)t->width; }
 
 int clear_canvas_impl(srt_tracer *t) {
@@ -288,6 +306,11 @@ int clear_canvas_impl(srt_tracer *t) {
 }
 
 } // namespace
+
+struct BvhCache {
+	std::vector<BvhCacheEntry> entries;
+};
+
 
 extern "C" {
 
@@ -419,6 +442,7 @@ void srt_destroy(srt_tracer *t) {
 	if (t->ev_k0) (void)hipEventDestroy(t->ev_k0);
 	if (t->ev_k1) (void)hipEventDestroy(t->ev_k1);
 	if (t->own_stream) (void)hipStreamDestroy(t->own_stream);
+	delete t->bvh_cache;
 	delete t;
 }
 
@@ -473,7 +497,10 @@ static int update_scene_impl(srt_tracer *t, const srt_shape *shapes, size_t n_sh
 	const bool use_bvh = t->accel_mode == SRT_ACCEL_BVH;
 	std::vector<BvhNode> bvh_nodes;
 	std::vector<uint32_t> bvh_order;
-	uint64_t bvh_leaves = 0, bvh_depth = 0;
+	uint64_t bvh_leaves = 0, bvh_depth = 0, bvh_reused = 0;
+	std::vector<BvhCacheEntry> next_cache;
+	if (use_bvh && !t->bvh_cache) t->bvh_cache = new BvhCache();
+	if (!use_bvh && t->bvh_cache) t->bvh_cache->entries.clear();
 	const auto build_t0 = std::chrono::steady_clock::now();
 	auto u2f = [](uint32_t u) {
 		float f;
@@ -522,10 +549,37 @@ static int update_scene_impl(srt_tracer *t, const srt_shape *shapes, size_t n_sh
 				return fail(t, SRT_ERR_INVALID, "srt_update_scene: too many world triangles");
 			uint32_t link = (uint32_t)total_wtris; // brute force: first world triangle of the model
 			if (use_bvh && m.num_triangles > 0) {
-				BvhBuilder bb(bvh_nodes, bvh_order);
-				link = bb.run(m, triangles, (uint32_t)total_wtris); // BVH: its root node
-				bvh_leaves += bb.leaves;
-				if (bb.max_depth > bvh_depth) bvh_depth = bb.max_depth;
+				BvhCacheEntry ent;
+				BvhCacheEntry *kept = nullptr;
+				for (BvhCacheEntry &e : t->bvh_cache->entries)
+					if (!e.nodes.empty() && e.matches(m, triangles)) {
+						kept = &e;
+						break;
+					}
+				if (kept) {
+					ent = std::move(*kept);
+					kept->nodes.clear();
+					bvh_reused++;
+				} else {
+					BvhBuilder bb(ent.nodes, ent.order);
+					bb.run(m, triangles, 0u);
+					ent.count = m.num_triangles;
+					memcpy(ent.transform, m.transform, sizeof ent.transform);
+					ent.tris.assign(triangles + m.triangle_index, triangles + m.triangle_index + m.num_triangles);
+					ent.leaves = bb.leaves, ent.depth = bb.max_depth;
+				}
+				// indices inside an entry are relative to its first node / first record
+				const uint32_t n0 = (uint32_t)bvh_nodes.size(), r0 = (uint32_t)total_wtris;
+				for (BvhNode nd : ent.nodes) {
+					if (nd.skip != SRT_BVH_END) nd.skip += n0;
+					if (nd.leaf) nd.leaf += r0; // the record index lives in the low 28 bits and r0 + records < 2^28 (checked above)
+					bvh_nodes.push_back(nd);
+				}
+				bvh_order.insert(bvh_order.end(), ent.order.begin(), ent.order.end());
+				link = n0; // BVH: its root node
+				bvh_leaves += ent.leaves;
+				if (ent.depth > bvh_depth) bvh_depth = ent.depth;
+				next_cache.push_back(std::move(ent));
 			}
 			data.insert(data.end(), {m.bounding_min.x, m.bounding_min.y, m.bounding_min.z, u2f(link), m.bounding_max.x, m.bounding_max.y,
 			                         m.bounding_max.z, u2f(m.num_triangles)});
@@ -616,6 +670,8 @@ static int update_scene_impl(srt_tracer *t, const srt_shape *shapes, size_t n_sh
 	t->num_models = num_models;
 	t->bvh_active = use_bvh && num_models > 0;
 	t->bvh_info[0] = bvh_nodes.size(), t->bvh_info[1] = bvh_leaves, t->bvh_info[2] = bvh_depth, t->bvh_info[3] = use_bvh ? build_us : 0;
+	t->bvh_info[4] = use_bvh ? next_cache.size() - bvh_reused : 0, t->bvh_info[5] = bvh_reused;
+	if (use_bvh) t->bvh_cache->entries = std::move(next_cache);
 	t->num_runs = (int)runs.size();
 	t->num_materials = n_materials;
 	t->scene_set = true;
@@ -1020,9 +1076,9 @@ int srt_bvh_build_host(const srt_shape *model, const srt_triangle *triangles, si
 	return SRT_OK;
 }
 
-int srt_acceleration_info(const srt_tracer *t, uint64_t out[4]) {
+int srt_acceleration_info(const srt_tracer *t, uint64_t out[6]) {
 	if (!t || !out) return SRT_ERR_INVALID;
-	for (int i = 0; i < 4; i++) out[i] = t->bvh_active ? t->bvh_info[i] : 0;
+	for (int i = 0; i < 6; i++) out[i] = t->bvh_active ? t->bvh_info[i] : 0;
 	return SRT_OK;
 }
 

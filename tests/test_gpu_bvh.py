@@ -174,6 +174,63 @@ def test_models_without_triangles_and_instances(T, sky):
     assert bits_equal(canv[1], canv[0]) and bits_equal(canv[2], canv[0]) and bits_equal(canv[3], canv[0])
 
 
+def test_unchanged_models_keep_their_hierarchy(T, sky):
+    """srt_update_scene re-uses the BVH of a model whose triangles and transform did not change
+    (camera / material / other-shape edits), rebuilds it when they did, and renders the same bits
+    either way."""
+    mesh = S.blob_mesh(12, 11, seed=4, smooth=True)
+    tris = R.concat(R.TRIANGLE, R.box_triangles(), mesh)
+    mats = np.zeros(2, R.MATERIAL)
+    mats[0] = R.material((0.7, 0.7, 0.9))
+    mats[1] = R.material((0.9, 0.5, 0.3), smoothness=0.4, specular=0.2)
+    shapes = np.zeros(3, R.SHAPE)
+    shapes[0] = R.plane(0, (0, -1.2, 0), (0, 1, 0))
+    shapes[1] = R.model(1, tris, 12, len(mesh), R.translate((-1.0, 0, 0)))
+    shapes[2] = R.box_model(0, 0, (1.5, -0.2, 0))
+    rd = R.render_data(96, 64, 2, 6, camera_to_world=S.default_camera(), time=99)
+    t = T.Tracer(96, 64)
+    t.set_skybox(sky)
+    t.set_acceleration(1)
+    t.options, t.scene_data = rd, R.scene_data(len(shapes))
+
+    def render():
+        t.clear_canvas()
+        t.trace()
+        return t.read_canvas()
+
+    t.update_scene(shapes, tris, mats)
+    i0 = t.acceleration_info()
+    assert (i0["models_built"], i0["models_reused"]) == (2, 0)
+    first = render()
+    mats2 = mats.copy()
+    mats2[1] = R.material((0.2, 0.9, 0.3))           # a material edit: both hierarchies are kept
+    t.update_scene(shapes, tris, mats2)
+    i1 = t.acceleration_info()
+    assert (i1["models_built"], i1["models_reused"]) == (0, 2) and i1["nodes"] == i0["nodes"]
+    t.update_scene(shapes, tris, mats)
+    assert bits_equal(render(), first)               # ... and are still the right ones
+    moved = shapes.copy()
+    moved[2] = R.box_model(0, 0, (1.7, -0.2, 0.3))   # the box moves: the mesh keeps its tree, the box gets a new one
+    t.update_scene(moved, tris, mats)
+    i2 = t.acceleration_info()
+    assert (i2["models_built"], i2["models_reused"]) == (1, 1)
+    got = render()
+    t.set_acceleration(0)
+    t.update_scene(moved, tris, mats)
+    assert bits_equal(got, render())
+    t.set_acceleration(1)
+    tris2 = tris.copy()
+    tris2["v"]["pos"][12 + 5, 1] += np.float32(0.01)  # one vertex of the mesh changes: rebuilt
+    t.update_scene(moved, tris2, mats)
+    i3 = t.acceleration_info()
+    assert (i3["models_built"], i3["models_reused"]) == (2, 0)  # (the cache was dropped by the array-scan update in between)
+    got = render()
+    t.set_acceleration(0)
+    t.update_scene(moved, tris2, mats)
+    assert bits_equal(got, render())
+    t.close()
+
+
 def test_random_scenes_with_bvh_match_oracle(sky, oracle, T):
     """The friendly half of the differential fuzzer (test_gpu_fuzz.py) through the BVH."""
     rng = np.random.RandomState(4711)

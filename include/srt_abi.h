@@ -86,10 +86,12 @@ int srt_update_scene(srt_tracer *t, const srt_shape *shapes, size_t n_shapes, co
 #define SRT_ACCEL_BVH 1
 int srt_set_acceleration(srt_tracer *t, int mode);
 /* out = {nodes, leaves, depth, host time spent on the hierarchies in microseconds, models built,
- * models re-used} for the current scene (zeros without SRT_ACCEL_BVH or without models). A model
- * whose triangles and transform are byte-identical to one of the previous srt_update_scene keeps
- * its hierarchy: editing the camera, materials or OTHER shapes does not pay the build again. */
-int srt_acceleration_info(const srt_tracer *t, uint64_t out[6]);
+ * models re-used, models refitted} for the current scene (zeros without SRT_ACCEL_BVH or without
+ * models). A model whose triangles are byte-identical to one of the previous srt_update_scene keeps
+ * its hierarchy: as it is when its transform did not change either (camera, material, other-shape
+ * edits cost no build), with new boxes around the same tree when it moved (a refit, ~10x cheaper
+ * than a build). */
+int srt_acceleration_info(const srt_tracer *t, uint64_t out[7]);
 
 /* Host-only (no device needed): the hierarchy srt_update_scene builds under SRT_ACCEL_BVH for ONE
  * model shape, for inspection and tests. `model->type` must be SRT_SHAPE_MODEL and its triangle

@@ -69,7 +69,7 @@ struct srt_tracer {
 	DevBuf<float> bvh_tris;
 	int accel_mode = SRT_ACCEL_NONE; // what the next srt_update_scene builds
 	bool bvh_active = false;         // the current scene's models carry BVH roots
-	uint64_t bvh_info[6] = {0, 0, 0, 0, 0, 0};
+	uint64_t bvh_info[7] = {0, 0, 0, 0, 0, 0, 0};
 	struct BvhCache *bvh_cache = nullptr; // hierarchies of the previous srt_update_scene (see BvhCacheEntry)
 	DevBuf<unsigned long long> counters;
 	DevBuf<unsigned long long> wave_counters; // per persistent wave, summed in srt_get_counters
@@ -266,6 +266,30 @@ struct BvhBuilder {
 		return self;
 	}
 
+	// New boxes for an existing topology (nodes relative to the model, `order` = triangle of each
+	// record): the model moved but its triangles did not. Children follow their parent in the
+	// array, so one backward sweep has every child's box ready before its parent's. O(n).
+	void refit(const srt_model &m, const srt_triangle *all) {
+		load(m, all);
+		const uint32_t n = (uint32_t)nodes.size();
+		for (uint32_t i = n; i-- > 0;) {
+			BvhNode &nd = nodes[i];
+			float lo[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, hi[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+			if (nd.leaf) {
+				const uint32_t first = nd.leaf & 0x0fffffffu, cnt = nd.leaf >> 28;
+				for (uint32_t r = first; r < first + cnt; r++) {
+					const Tri &t = tris[order[r]]; // load() leaves tris in triangle order
+					for (int a = 0; a < 3; a++) lo[a] = std::min(lo[a], t.lo[a]), hi[a] = std::max(hi[a], t.hi[a]);
+				}
+			} else {
+				const uint32_t left = i + 1, right = nodes[left].skip == SRT_BVH_END ? n : nodes[left].skip;
+				for (uint32_t c : {left, right})
+					for (int a = 0; a < 3; a++) lo[a] = std::min(lo[a], nodes[c].lo[a]), hi[a] = std::max(hi[a], nodes[c].hi[a]);
+			}
+			for (int a = 0; a < 3; a++) nd.lo[a] = lo[a], nd.hi[a] = hi[a];
+		}
+	}
+
 	// Appends the model's nodes and triangle order; returns the root's index.
 	uint32_t run(const srt_model &m, const srt_triangle *all, uint32_t first_record) {
 		rec_base = first_record;
@@ -291,10 +315,10 @@ struct BvhCacheEntry {
 	std::vector<BvhNode> nodes;
 	std::vector<uint32_t> order;
 	uint32_t leaves = 0, depth = 0;
-	bool matches(const srt_model &m, const srt_triangle *all) const {
-		return m.num_triangles == count && memcmp(transform, m.transform, sizeof transform) == 0 &&
-		       memcmp(tris.data(), all + m.triangle_index, (size_t)count * sizeof(srt_triangle)) == 0;
+	bool same_triangles(const srt_model &m, const srt_triangle *all) const {
+		return m.num_triangles == count && memcmp(tris.data(), all + m.triangle_index, (size_t)count * sizeof(srt_triangle)) == 0;
 	}
+	bool same_transform(const srt_model &m) const { return memcmp(transform, m.transform, sizeof transform) == 0; }
 };
 
 size_t owned_pixels(const srt_tracer *t) { return (size_t)t->owned_rows * (size_t)t->width; }
@@ -497,7 +521,7 @@ static int update_scene_impl(srt_tracer *t, const srt_shape *shapes, size_t n_sh
 	const bool use_bvh = t->accel_mode == SRT_ACCEL_BVH;
 	std::vector<BvhNode> bvh_nodes;
 	std::vector<uint32_t> bvh_order;
-	uint64_t bvh_leaves = 0, bvh_depth = 0, bvh_reused = 0;
+	uint64_t bvh_leaves = 0, bvh_depth = 0, bvh_reused = 0, bvh_refitted = 0;
 	std::vector<BvhCacheEntry> next_cache;
 	if (use_bvh && !t->bvh_cache) t->bvh_cache = new BvhCache();
 	if (!use_bvh && t->bvh_cache) t->bvh_cache->entries.clear();
@@ -551,15 +575,22 @@ static int update_scene_impl(srt_tracer *t, const srt_shape *shapes, size_t n_sh
 			if (use_bvh && m.num_triangles > 0) {
 				BvhCacheEntry ent;
 				BvhCacheEntry *kept = nullptr;
-				for (BvhCacheEntry &e : t->bvh_cache->entries)
-					if (!e.nodes.empty() && e.matches(m, triangles)) {
+				for (BvhCacheEntry &e : t->bvh_cache->entries) // same triangles; prefer the one that did not move either
+					if (!e.nodes.empty() && e.same_triangles(m, triangles) && (!kept || e.same_transform(m))) {
 						kept = &e;
-						break;
+						if (e.same_transform(m)) break;
 					}
 				if (kept) {
 					ent = std::move(*kept);
 					kept->nodes.clear();
-					bvh_reused++;
+					if (ent.same_transform(m)) {
+						bvh_reused++;
+					} else { // the model moved: keep the topology, recompute the boxes
+						BvhBuilder bb(ent.nodes, ent.order);
+						bb.refit(m, triangles);
+						memcpy(ent.transform, m.transform, sizeof ent.transform);
+						bvh_refitted++;
+					}
 				} else {
 					BvhBuilder bb(ent.nodes, ent.order);
 					bb.run(m, triangles, 0u);
@@ -670,7 +701,7 @@ static int update_scene_impl(srt_tracer *t, const srt_shape *shapes, size_t n_sh
 	t->num_models = num_models;
 	t->bvh_active = use_bvh && num_models > 0;
 	t->bvh_info[0] = bvh_nodes.size(), t->bvh_info[1] = bvh_leaves, t->bvh_info[2] = bvh_depth, t->bvh_info[3] = use_bvh ? build_us : 0;
-	t->bvh_info[4] = use_bvh ? next_cache.size() - bvh_reused : 0, t->bvh_info[5] = bvh_reused;
+	t->bvh_info[4] = use_bvh ? next_cache.size() - bvh_reused - bvh_refitted : 0, t->bvh_info[5] = bvh_reused, t->bvh_info[6] = bvh_refitted;
 	if (use_bvh) t->bvh_cache->entries = std::move(next_cache);
 	t->num_runs = (int)runs.size();
 	t->num_materials = n_materials;
@@ -1076,9 +1107,9 @@ int srt_bvh_build_host(const srt_shape *model, const srt_triangle *triangles, si
 	return SRT_OK;
 }
 
-int srt_acceleration_info(const srt_tracer *t, uint64_t out[6]) {
+int srt_acceleration_info(const srt_tracer *t, uint64_t out[7]) {
 	if (!t || !out) return SRT_ERR_INVALID;
-	for (int i = 0; i < 6; i++) out[i] = t->bvh_active ? t->bvh_info[i] : 0;
+	for (int i = 0; i < 7; i++) out[i] = t->bvh_active ? t->bvh_info[i] : 0;
 	return SRT_OK;
 }
 

@@ -236,9 +236,9 @@ class Tracer:
         self._check(self.lib.srt_set_acceleration(self._h, int(mode)))
 
     def acceleration_info(self):
-        out = (C.c_uint64 * 6)()
+        out = (C.c_uint64 * 7)()
         self._check(self.lib.srt_acceleration_info(self._h, out))
-        return dict(zip(("nodes", "leaves", "depth", "build_us", "models_built", "models_reused"), (int(v) for v in out)))
+        return dict(zip(("nodes", "leaves", "depth", "build_us", "models_built", "models_reused", "models_refitted"), (int(v) for v in out)))
 
     def selftest_math(self, stride=1):
         out = (C.c_uint64 * 12)()

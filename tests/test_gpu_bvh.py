@@ -210,10 +210,11 @@ def test_unchanged_models_keep_their_hierarchy(T, sky):
     t.update_scene(shapes, tris, mats)
     assert bits_equal(render(), first)               # ... and are still the right ones
     moved = shapes.copy()
-    moved[2] = R.box_model(0, 0, (1.7, -0.2, 0.3))   # the box moves: the mesh keeps its tree, the box gets a new one
-    t.update_scene(moved, tris, mats)
+    moved[2] = R.box_model(0, 0, (1.7, -0.2, 0.3))   # the box moves: the mesh keeps its tree, the box's is refitted
+    moved[1] = R.model(1, tris, 12, len(mesh), R.mat_mul(R.translate((-1.1, 0.2, 0.1)), R.mat_mul(R.euler_yxz(0.8, -0.4, 0.3), R.scale_matrix((1.2, 0.7, 1.0)))))
+    t.update_scene(moved, tris, mats)                # ... and the mesh is rotated and squashed: refitted, too
     i2 = t.acceleration_info()
-    assert (i2["models_built"], i2["models_reused"]) == (1, 1)
+    assert (i2["models_built"], i2["models_reused"], i2["models_refitted"]) == (0, 0, 2) and i2["nodes"] == i0["nodes"]
     got = render()
     t.set_acceleration(0)
     t.update_scene(moved, tris, mats)
@@ -223,7 +224,7 @@ def test_unchanged_models_keep_their_hierarchy(T, sky):
     tris2["v"]["pos"][12 + 5, 1] += np.float32(0.01)  # one vertex of the mesh changes: rebuilt
     t.update_scene(moved, tris2, mats)
     i3 = t.acceleration_info()
-    assert (i3["models_built"], i3["models_reused"]) == (2, 0)  # (the cache was dropped by the array-scan update in between)
+    assert (i3["models_built"], i3["models_reused"], i3["models_refitted"]) == (2, 0, 0)  # (the cache was dropped by the array-scan update in between)
     got = render()
     t.set_acceleration(0)
     t.update_scene(moved, tris2, mats)

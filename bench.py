@@ -2,7 +2,11 @@
 """bench.py — headline metric of BASELINE.json: Mray/s of the path-tracing hot path.
 
   python bench.py [--gpus N] [--steps K] [--warmup W] [--workload NAME]
-  (N > 1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
+  N > 1 either way: `python bench.py --gpus N ...` starts its own N ranks (children of
+  `python -m torch.distributed.run`, before this process has touched a GPU), and
+  `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
+  --master-port P bench.py --gpus N ...` (the driver's form) is used as it comes.
+  The documented 8-GPU line is BASELINE configs[3]: --gpus 8 --workload spheres_4k_4096spp.
 
 Step   = one dispatch of the hot path over the whole frame of the workload: clear the
          accumulation canvas, trace (the `render` kernel), [N > 1: ONE gather of the
@@ -71,7 +75,45 @@ def w_bytes(c, pixels, scene_bytes, sky_bytes):
     return 24 * c["paths"] + 32 * pixels + scene_bytes + min(sky_bytes, 64 * c["sky"])
 
 
-def cpu_baseline(name, sky, target_seconds=15.0):
+def w_bytes_survey(c, pixels, scene_bytes, sky_bytes):
+    """SURVEY.md §8(d) W_bytes: what the ALGORITHM has to move (canvas RMW 32 B + resolve 20 B per pixel, scene, touched
+    sky texels) -- without the per-path radiance spill this design adds to keep the sample sum ordered."""
+    return 52 * pixels + scene_bytes + min(sky_bytes, 64 * c["sky"])
+
+
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def same_bits(a, b):
+    """bit compare of float arrays, NaN == NaN"""
+    na, nb = np.isnan(a), np.isnan(b)
+    return bool(np.array_equal(na, nb) and np.array_equal(a.view(np.uint32)[~na], b.view(np.uint32)[~nb]))
+
+
+def self_launch(argv, n):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as children of
+    torch.distributed.run and pass their exit code on. Runs before this process has made any HIP
+    call (never re-exec or fork a process that has initialised the GPU)."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), str(Path(__file__).resolve())] + argv
+    return subprocess.run(cmd, env=env).returncode
+
+
+def cpu_baseline(name, sky, target_seconds=15.0, spp_override=0):
     """CPU rate on the host cores over a sample of the SAME frame (same scene, seeds, spp).
     When oracle/_ref/libsrt_ref.so is present (the reference's own render.cl compiled for
     x86-64, built where /root/reference exists and shipped prebuilt) it is what gets timed
@@ -82,6 +124,7 @@ def cpu_baseline(name, sky, target_seconds=15.0):
     oracle_py.build()
     orc = oracle_py.Oracle("oracle")
     builder, w, h, spp, nb, _ = WORKLOADS[name]
+    spp = spp_override or spp
     shapes, tris, mats = builder()
     rd = R.render_data(w, h, spp, nb, camera_to_world=S.default_camera(), time=12345)
     sd = R.scene_data(len(shapes))
@@ -110,6 +153,7 @@ def cpu_baseline(name, sky, target_seconds=15.0):
         rays = paths = 0
         dt_port = dt_ref = 0.0
         same = True
+        port_rows = {}
         for y0, y1 in bands:
             t0 = time.time()
             cp, c = orc.render(rd, sd, shapes, tris, mats, sky, rows=(y0, y1), nthreads=threads, counters=True)
@@ -119,11 +163,12 @@ def cpu_baseline(name, sky, target_seconds=15.0):
             dt_ref += time.time() - t0
             rays += c["rays"]
             paths += c["paths"]
+            port_rows[(y0, y1)] = cp[y0:y1, :, :3].copy()
             a, b = cp[y0:y1, :, :3], cr[y0:y1, :, :3]  # the float3's padding lane is unspecified (the reference build carries NaNs into it)
             same = same and bool(np.array_equal(np.isnan(a), np.isnan(b)) and np.array_equal(a.view(np.uint32)[~np.isnan(a)], b.view(np.uint32)[~np.isnan(b)]))
         n_rows = sum(y1 - y0 for y0, y1 in bands)
         return {
-            "value": round(rays / dt_ref / 1e6, 3), "unit": "Mray/s", "cores": threads, "kind": "reference",
+            "value": round(rays / dt_ref / 1e6, 3), "unit": "Mray/s", "cores": threads, "cpu_model": cpu_model(), "kind": "reference", "_port_rows": port_rows,
             "sample": f"oracle/_ref/libsrt_ref.so (the reference's src/render.cl compiled for x86-64, OpenMP over pixels), {len(bands)} bands of {band} rows spread over the frame ({n_rows} of {h} rows x {w} px x {spp} spp = {paths} paths, {rays} rays counted by the port on the same rows) in {dt_ref:.1f} s; the port took {dt_port:.1f} s on the same rows and its canvas is {'bit-identical' if same else 'DIFFERENT'}",
             "mpath_per_s": round(paths / dt_ref / 1e6, 3), "port_value": round(rays / dt_port / 1e6, 3), "reference_equals_port": same,
         }
@@ -131,11 +176,12 @@ def cpu_baseline(name, sky, target_seconds=15.0):
     stride = max(1, h // rows_wanted)
     y0 = stride // 2
     t0 = time.time()
-    _, c = orc.render(rd, sd, shapes, tris, mats, sky, rows=(y0, h), row_stride=stride, nthreads=threads, counters=True)
+    cp, c = orc.render(rd, sd, shapes, tris, mats, sky, rows=(y0, h), row_stride=stride, nthreads=threads, counters=True)
     dt = time.time() - t0
     n_rows = len(range(y0, h, stride))
+    port_rows = {(y, y + 1): cp[y:y + 1, :, :3].copy() for y in range(y0, h, stride)}
     return {
-        "value": round(c["rays"] / dt / 1e6, 3), "unit": "Mray/s", "cores": threads, "kind": "port",
+        "value": round(c["rays"] / dt / 1e6, 3), "unit": "Mray/s", "cores": threads, "cpu_model": cpu_model(), "kind": "port", "_port_rows": port_rows,
         "sample": f"oracle/srt_oracle.c (bit-identical port of render.cl), rows {y0}::{stride} ({n_rows} of {h} rows x {w} px x {spp} spp = {c['paths']} paths, {c['rays']} rays) in {dt:.1f} s",
         "mpath_per_s": round(c["paths"] / dt / 1e6, 3),
     }
@@ -160,8 +206,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
+        if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+            raise SystemExit(self_launch(sys.argv[1:], args.gpus))  # nothing above has touched a GPU
         args.gpus = world
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
@@ -262,8 +308,8 @@ def main():
     rays, paths, nsky, nan_px = (int(v) for v in cnt.tolist())
 
     check = None
-    if rank == 0 and os.environ.get("SRT_BENCH_CHECK") and world > 1:
-        # rehearsal aid: the gathered, unpermuted canvas must equal a single-handle render bit for bit
+    if rank == 0 and world > 1 and os.environ.get("SRT_BENCH_CHECK", "1") != "0":
+        # outside the timed region: the gathered, unpermuted canvas must equal a single-handle render of the whole frame bit for bit
         ref_t = T.Tracer(w, h, device=local_rank)
         ref_t.set_skybox(sky)
         ref_t.options, ref_t.scene_data = t.options.copy(), t.scene_data.copy()
@@ -272,8 +318,7 @@ def main():
         ref_t.trace()
         want = ref_t.read_canvas()
         got = step.full.cpu().numpy()
-        nan_w, nan_g = np.isnan(want), np.isnan(got)
-        check = bool(np.array_equal(nan_w, nan_g) and np.array_equal(want.view(np.uint32)[~nan_w], got.view(np.uint32)[~nan_g]))
+        check = same_bits(want, got)
         ref_t.close()
     if rank == 0:
         steps = max(args.steps, 1)
@@ -290,6 +335,7 @@ def main():
         ops = w_ops(per, shapes)
         scene_bytes = shapes.nbytes + tris.nbytes + mats.nbytes
         nbytes = w_bytes(per, w * h, scene_bytes, sky.nbytes)
+        nbytes_alg = w_bytes_survey(per, w * h, scene_bytes, sky.nbytes)
         kt = trace_ms_max * 1e-3 if trace_ms_max > 0 else elapsed_max / steps
         achieved = ops / kt / 1e12 / world  # per-GPU rate: each GPU ran 1/world of the ops in kt
         traffic = None
@@ -327,14 +373,29 @@ def main():
                 "kernel": "srt_trace_kernel", "algorithmic_ops_per_launch": int(ops // world),
                 "note": "VALU-issue roofline (SURVEY.md §8d/H8): 256 CU x 4 SIMD x 32 lanes x 2.4 GHz; ops = W_ops formula over exact kernel counters",
                 "hbm": {"achieved": round(nbytes / world / kt / 1e9, 2), "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                        "frac": round(nbytes / world / kt / HBM_PEAK, 6), "algorithmic_bytes_per_launch": int(nbytes // world)},
+                        "frac": round(nbytes / world / kt / HBM_PEAK, 6), "design_bytes_per_launch": int(nbytes // world),
+                        "algorithmic_bytes_per_launch": int(nbytes_alg // world),
+                        "note": "design bytes = algorithmic bytes (SURVEY.md 8d W_bytes) + 24 B per path of radiance written by the trace kernel and read by the ordered reduction"},
             },
         }
+        ok = True
         if check is not None:
             line["gathered_equals_single_gpu"] = check
+            ok = ok and check
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(args.workload, sky)
+            cb = cpu_baseline(args.workload, sky, spp_override=args.spp)
+            # the frame that was TIMED, checked where the CPU has already rendered it: the canvas of the last timed step
+            # (one dispatch at the workload's full spp) against the port's rows, bit for bit
+            port_rows = cb.pop("_port_rows")
+            gpu = canvas_t.cpu().numpy()
+            cb["gpu_equals_port"] = all(same_bits(gpu[y0:y1, :, :3], rows) for (y0, y1), rows in port_rows.items())
+            cb["gpu_rows_checked"] = int(sum(y1 - y0 for y0, y1 in port_rows))
+            line["cpu_baseline"] = cb
+            ok = ok and cb["gpu_equals_port"] and cb.get("reference_equals_port", True)
         print(json.dumps(line), flush=True)
+        if not ok:
+            t.close()
+            raise SystemExit("bench.py: the timed canvas differs from its checker (see gpu_equals_port / gathered_equals_single_gpu in the line above)")
     t.close()
     if world > 1:
         dist.destroy_process_group()

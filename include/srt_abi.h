@@ -153,8 +153,8 @@ int srt_reset_counters(srt_tracer *t);
  * the most recent resolve, from HIP events recorded on the handle's stream (milliseconds).
  * Synchronises the stream. */
 int srt_last_kernel_ms(srt_tracer *t, float *trace_ms, float *resolve_ms);
-/* The same for srt_trace_kernel alone: first launch start to last launch end (with one
- * sample batch, the usual case, exactly that one kernel; reductions excluded). */
+/* The same for srt_trace_kernel alone: the sum over the dispatch's sample batches of each
+ * launch's own event pair (the ordered reductions between batches are not counted). */
 int srt_last_trace_kernel_ms(srt_tracer *t, float *kernel_ms);
 /* Device pointers of the handle's buffers, for zero-copy hand-off (e.g. to a
  * torch.distributed gather): canvas = owned_rows*width*16 B, argb = owned_rows*width*4 B. */

@@ -12,7 +12,9 @@ trace time with it off (profiles/README.md). It reorders nothing, so results are
 """
 import contextlib
 import fcntl
+import json
 import os
+import re
 import shutil
 import subprocess
 from pathlib import Path
@@ -24,7 +26,39 @@ LIB = LIBDIR / "libsrt_hip.so"
 SOURCES = ["kernels.hip", "srt_abi.hip"]
 HEADERS = ["detmath.h", "device_types.h", "../../include/srt_abi.h", "../../include/srt_types.h"]
 ARCH = "gfx950"
-FLAGS = ["-O3", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize", "-fPIC", "-fno-gpu-rdc", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function"]
+FLAGS = ["-O3", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize", "-fPIC", "-fno-gpu-rdc", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function",
+         "-Rpass-analysis=kernel-resource-usage"]
+RESOURCES = LIBDIR / "kernel_resources.json"  # registers / spills / scratch per kernel instantiation of the last build
+
+
+def parse_resource_remarks(stderr):
+    """{demangled-ish kernel name: {sgprs, vgprs, scratch, occupancy, sgpr_spill, vgpr_spill, lds}} from the
+    -Rpass-analysis=kernel-resource-usage remarks of one hipcc run."""
+    out, cur = {}, None
+    keys = {"TotalSGPRs": "sgprs", "VGPRs": "vgprs", "AGPRs": "agprs", "ScratchSize [bytes/lane]": "scratch_bytes_per_lane",
+            "Occupancy [waves/SIMD]": "occupancy_waves_per_simd", "SGPRs Spill": "sgpr_spill", "VGPRs Spill": "vgpr_spill",
+            "LDS Size [bytes/block]": "lds_bytes"}
+    for line in stderr.splitlines():
+        m = re.search(r"remark: Function Name: (\S+)", line)
+        if m:
+            name = m.group(1)
+            try:
+                name = subprocess.run(["c++filt", name], capture_output=True, text=True).stdout.strip() or name
+            except OSError:
+                pass
+            cur = out.setdefault(name.split("(")[0].replace("void ", ""), {})
+            continue
+        m = re.search(r"remark:\s+([A-Za-z \[\]/]+): (\d+) \[-Rpass", line)
+        if m and cur is not None and m.group(1).strip() in keys:
+            cur[keys[m.group(1).strip()]] = int(m.group(2))
+    return out
+
+
+def print_resources(res=None):
+    res = res if res is not None else (json.loads(RESOURCES.read_text()) if RESOURCES.exists() else {})
+    for name, r in sorted(res.items()):
+        print(f"  {name}: {r.get('vgprs')} VGPR, {r.get('sgprs')} SGPR, spills {r.get('sgpr_spill')} SGPR / {r.get('vgpr_spill')} VGPR, "
+              f"scratch {r.get('scratch_bytes_per_lane')} B/lane, occupancy {r.get('occupancy_waves_per_simd')}")
 
 
 def hipcc():
@@ -79,8 +113,11 @@ def build_hip(force=False, verbose=False, extra_flags=()):
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("hipcc failed:\n" + r.stdout + r.stderr)
-        if verbose and r.stderr:
-            print(r.stderr)
+        res = parse_resource_remarks(r.stderr)
+        RESOURCES.write_text(json.dumps(res, indent=1, sort_keys=True))
+        if verbose:
+            print("\n".join(l for l in r.stderr.splitlines() if "warning" in l or "error" in l))
+            print_resources(res)
         os.replace(tmp, LIB)  # atomic: a concurrent dlopen sees the old or the new file, never half of one
     return LIB
 

@@ -10,6 +10,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <deque>
 #include <new>
 #include <string>
 #include <vector>
@@ -77,7 +78,8 @@ struct srt_tracer {
 	DevBuf<float> running;   // float4 per pixel, carries the ordered sum across batches
 	size_t radiance_budget = 0; // bytes; 0 = pick from free HBM at first use
 	int num_cus = 0;
-	hipEvent_t ev_k0 = nullptr, ev_k1 = nullptr; // around the trace KERNELS only (reduce excluded)
+	std::vector<hipEvent_t> ev_k; // one pair per sample batch, around srt_trace_kernel alone (reduce excluded)
+	size_t ev_k_used = 0;         // events of the last srt_trace
 	float last_trace_kernel_ms = 0.f, last_reduce_ms = 0.f;
 	int sky_w = 0, sky_h = 0;
 	srt_scene_data sd{};
@@ -310,16 +312,30 @@ struct BvhBuilder {
 // the build again (10^5 triangles: 37 ms -> 1.5 ms for the comparison).
 struct BvhCacheEntry {
 	uint32_t count = 0;
+	uint64_t tri_hash = 0; // of the triangle bytes: looked at before any memcmp
+	bool claimed = false;  // taken by a model of the srt_update_scene in progress
 	srt_float4 transform[4];
 	std::vector<srt_triangle> tris;
 	std::vector<BvhNode> nodes;
 	std::vector<uint32_t> order;
 	uint32_t leaves = 0, depth = 0;
-	bool same_triangles(const srt_model &m, const srt_triangle *all) const {
-		return m.num_triangles == count && memcmp(tris.data(), all + m.triangle_index, (size_t)count * sizeof(srt_triangle)) == 0;
+	bool same_triangles(const srt_model &m, const srt_triangle *all, uint64_t hash) const {
+		return m.num_triangles == count && hash == tri_hash && memcmp(tris.data(), all + m.triangle_index, (size_t)count * sizeof(srt_triangle)) == 0;
 	}
 	bool same_transform(const srt_model &m) const { return memcmp(transform, m.transform, sizeof transform) == 0; }
 };
+
+// 64-bit FNV-1a over 8-byte words (records are 96 B)
+uint64_t hash_triangles(const srt_triangle *tris, size_t count) {
+	uint64_t h = 0xcbf29ce484222325ull;
+	const size_t words = count * sizeof(srt_triangle) / 8;
+	for (size_t i = 0; i < words; i++) {
+		uint64_t w;
+		memcpy(&w, reinterpret_cast<const char *>(tris) + 8 * i, 8);
+		h = (h ^ w) * 0x100000001b3ull;
+	}
+	return h;
+}
 
 size_t owned_pixels(const srt_tracer *t) { return (size_t)t->owned_rows * (size_t)t->width; }
 
@@ -424,8 +440,7 @@ int srt_create(int width, int height, int device_index, srt_tracer **out) {
 	    (e = t->wtris.reserve(SRT_WTRI_FLOATS + 64)) != hipSuccess || (e = t->wtri_offset.reserve(1)) != hipSuccess)
 		return bail("scene alloc", e);
 	if ((e = hipEventCreate(&t->ev_t0)) != hipSuccess || (e = hipEventCreate(&t->ev_t1)) != hipSuccess ||
-	    (e = hipEventCreate(&t->ev_r0)) != hipSuccess || (e = hipEventCreate(&t->ev_r1)) != hipSuccess ||
-	    (e = hipEventCreate(&t->ev_k0)) != hipSuccess || (e = hipEventCreate(&t->ev_k1)) != hipSuccess)
+	    (e = hipEventCreate(&t->ev_r0)) != hipSuccess || (e = hipEventCreate(&t->ev_r1)) != hipSuccess)
 		return bail("hipEventCreate", e);
 	if ((e = hipMemsetAsync(t->canvas, 0, t->canvas_bytes, t->stream)) != hipSuccess) return bail("canvas clear", e);
 	if ((e = hipMemsetAsync(t->wave_counters.ptr, 0, (size_t)SRT_WAVE_CTR_SLOTS * SRT_WAVE_CTR_STRIDE * sizeof(unsigned long long), t->stream)) != hipSuccess)
@@ -463,8 +478,7 @@ void srt_destroy(srt_tracer *t) {
 	if (t->ev_t1) (void)hipEventDestroy(t->ev_t1);
 	if (t->ev_r0) (void)hipEventDestroy(t->ev_r0);
 	if (t->ev_r1) (void)hipEventDestroy(t->ev_r1);
-	if (t->ev_k0) (void)hipEventDestroy(t->ev_k0);
-	if (t->ev_k1) (void)hipEventDestroy(t->ev_k1);
+	for (hipEvent_t ev : t->ev_k) (void)hipEventDestroy(ev);
 	if (t->own_stream) (void)hipStreamDestroy(t->own_stream);
 	delete t->bvh_cache;
 	delete t;
@@ -522,8 +536,12 @@ static int update_scene_impl(srt_tracer *t, const srt_shape *shapes, size_t n_sh
 	std::vector<BvhNode> bvh_nodes;
 	std::vector<uint32_t> bvh_order;
 	uint64_t bvh_leaves = 0, bvh_depth = 0, bvh_reused = 0, bvh_refitted = 0;
-	std::vector<BvhCacheEntry> next_cache;
+	std::deque<BvhCacheEntry> fresh;                 // hierarchies built by this call (deque: growth keeps references valid)
+	std::vector<std::pair<bool, size_t>> plan;       // per model with triangles: {from the cache?, index there / in fresh}
+	std::vector<std::pair<uint64_t, uint64_t>> range_hashes; // {triangle_index << 32 | count, hash}
 	if (use_bvh && !t->bvh_cache) t->bvh_cache = new BvhCache();
+	if (t->bvh_cache)
+		for (BvhCacheEntry &e : t->bvh_cache->entries) e.claimed = false;
 	if (!use_bvh && t->bvh_cache) t->bvh_cache->entries.clear();
 	const auto build_t0 = std::chrono::steady_clock::now();
 	auto u2f = [](uint32_t u) {
@@ -573,44 +591,64 @@ static int update_scene_impl(srt_tracer *t, const srt_shape *shapes, size_t n_sh
 				return fail(t, SRT_ERR_INVALID, "srt_update_scene: too many world triangles");
 			uint32_t link = (uint32_t)total_wtris; // brute force: first world triangle of the model
 			if (use_bvh && m.num_triangles > 0) {
-				BvhCacheEntry ent;
+				// hash of this triangle range, once per distinct range per call (instances share ranges)
+				uint64_t th = 0;
+				bool have_hash = false;
+				for (const auto &rh : range_hashes)
+					if (rh.first == (((uint64_t)m.triangle_index << 32) | m.num_triangles)) th = rh.second, have_hash = true;
+				if (!have_hash) {
+					th = hash_triangles(triangles + m.triangle_index, m.num_triangles);
+					range_hashes.emplace_back(((uint64_t)m.triangle_index << 32) | m.num_triangles, th);
+				}
+				// An entry of the previous call with the same triangles: as it is when the transform did not
+				// change either, otherwise refitted. Hash and transform are compared before any memcmp, and
+				// entries only LEAVE the cache once the whole shape loop has validated (an early error return
+				// keeps every hierarchy).
 				BvhCacheEntry *kept = nullptr;
-				for (BvhCacheEntry &e : t->bvh_cache->entries) // same triangles; prefer the one that did not move either
-					if (!e.nodes.empty() && e.same_triangles(m, triangles) && (!kept || e.same_transform(m))) {
-						kept = &e;
-						if (e.same_transform(m)) break;
-					}
+				for (BvhCacheEntry &e : t->bvh_cache->entries) {
+					if (e.claimed || e.count != m.num_triangles || e.tri_hash != th) continue;
+					const bool exact = e.same_transform(m);
+					if (!exact && kept) continue; // already holding a refit candidate: only an exact match improves on it
+					if (!e.same_triangles(m, triangles, th)) continue;
+					kept = &e;
+					if (exact) break;
+				}
+				BvhCacheEntry *ent;
 				if (kept) {
-					ent = std::move(*kept);
-					kept->nodes.clear();
-					if (ent.same_transform(m)) {
+					ent = kept;
+					ent->claimed = true;
+					if (ent->same_transform(m)) {
 						bvh_reused++;
 					} else { // the model moved: keep the topology, recompute the boxes
-						BvhBuilder bb(ent.nodes, ent.order);
+						BvhBuilder bb(ent->nodes, ent->order);
 						bb.refit(m, triangles);
-						memcpy(ent.transform, m.transform, sizeof ent.transform);
+						memcpy(ent->transform, m.transform, sizeof ent->transform);
 						bvh_refitted++;
 					}
+					plan.emplace_back(true, (size_t)(kept - t->bvh_cache->entries.data()));
 				} else {
-					BvhBuilder bb(ent.nodes, ent.order);
+					fresh.emplace_back();
+					ent = &fresh.back();
+					BvhBuilder bb(ent->nodes, ent->order);
 					bb.run(m, triangles, 0u);
-					ent.count = m.num_triangles;
-					memcpy(ent.transform, m.transform, sizeof ent.transform);
-					ent.tris.assign(triangles + m.triangle_index, triangles + m.triangle_index + m.num_triangles);
-					ent.leaves = bb.leaves, ent.depth = bb.max_depth;
+					ent->count = m.num_triangles;
+					ent->tri_hash = th;
+					memcpy(ent->transform, m.transform, sizeof ent->transform);
+					ent->tris.assign(triangles + m.triangle_index, triangles + m.triangle_index + m.num_triangles);
+					ent->leaves = bb.leaves, ent->depth = bb.max_depth;
+					plan.emplace_back(false, fresh.size() - 1);
 				}
 				// indices inside an entry are relative to its first node / first record
 				const uint32_t n0 = (uint32_t)bvh_nodes.size(), r0 = (uint32_t)total_wtris;
-				for (BvhNode nd : ent.nodes) {
+				for (BvhNode nd : ent->nodes) {
 					if (nd.skip != SRT_BVH_END) nd.skip += n0;
 					if (nd.leaf) nd.leaf += r0; // the record index lives in the low 28 bits and r0 + records < 2^28 (checked above)
 					bvh_nodes.push_back(nd);
 				}
-				bvh_order.insert(bvh_order.end(), ent.order.begin(), ent.order.end());
+				bvh_order.insert(bvh_order.end(), ent->order.begin(), ent->order.end());
 				link = n0; // BVH: its root node
-				bvh_leaves += ent.leaves;
-				if (ent.depth > bvh_depth) bvh_depth = ent.depth;
-				next_cache.push_back(std::move(ent));
+				bvh_leaves += ent->leaves;
+				if (ent->depth > bvh_depth) bvh_depth = ent->depth;
 			}
 			data.insert(data.end(), {m.bounding_min.x, m.bounding_min.y, m.bounding_min.z, u2f(link), m.bounding_max.x, m.bounding_max.y,
 			                         m.bounding_max.z, u2f(m.num_triangles)});
@@ -701,8 +739,13 @@ static int update_scene_impl(srt_tracer *t, const srt_shape *shapes, size_t n_sh
 	t->num_models = num_models;
 	t->bvh_active = use_bvh && num_models > 0;
 	t->bvh_info[0] = bvh_nodes.size(), t->bvh_info[1] = bvh_leaves, t->bvh_info[2] = bvh_depth, t->bvh_info[3] = use_bvh ? build_us : 0;
-	t->bvh_info[4] = use_bvh ? next_cache.size() - bvh_reused - bvh_refitted : 0, t->bvh_info[5] = bvh_reused, t->bvh_info[6] = bvh_refitted;
-	if (use_bvh) t->bvh_cache->entries = std::move(next_cache);
+	t->bvh_info[4] = use_bvh ? plan.size() - bvh_reused - bvh_refitted : 0, t->bvh_info[5] = bvh_reused, t->bvh_info[6] = bvh_refitted;
+	if (use_bvh) {
+		std::vector<BvhCacheEntry> next_cache;
+		next_cache.reserve(plan.size());
+		for (const auto &pl : plan) next_cache.push_back(std::move(pl.first ? t->bvh_cache->entries[pl.second] : fresh[pl.second]));
+		t->bvh_cache->entries = std::move(next_cache);
+	}
 	t->num_runs = (int)runs.size();
 	t->num_materials = n_materials;
 	t->scene_set = true;
@@ -805,6 +848,17 @@ int srt_trace(srt_tracer *t, const srt_render_data *options) {
 	rp.num_pixels = (uint32_t)pixels;
 	rp.num_samples = ns;
 
+	while (t->ev_k.size() < 2 * (size_t)n_batches) { // std::vector growth is the only throwing step: srt_trace's callers catch nothing
+		hipEvent_t ev = nullptr;
+		SRT_HIP(t, hipEventCreate(&ev));
+		try {
+			t->ev_k.push_back(ev);
+		} catch (...) {
+			(void)hipEventDestroy(ev);
+			return fail(t, SRT_ERR_INVALID, "out of host memory");
+		}
+	}
+	t->ev_k_used = 0;
 	SRT_HIP(t, hipEventRecord(t->ev_t0, t->stream));
 	if (n_batches == 0) {
 		// num_samples <= 0: no paths; the reduction still applies colour = 0 / num_samples (render.cl:520-522)
@@ -838,10 +892,11 @@ int srt_trace(srt_tracer *t, const srt_render_data *options) {
 		const unsigned long long waves_needed = (p.total_items + 63ull) / 64ull;
 		const int num_waves = (int)(waves_needed < slots_b ? waves_needed : slots_b);
 		SRT_HIP(t, hipMemsetAsync(p.queue, 0, sizeof(unsigned long long), t->stream));
-		if (b == 0) SRT_HIP(t, hipEventRecord(t->ev_k0, t->stream));
+		SRT_HIP(t, hipEventRecord(t->ev_k[2 * b], t->stream));
 		srt_launch_trace(p, t->count_tris, num_waves, t->stream);
 		SRT_HIP(t, hipGetLastError());
-		if (b == n_batches - 1) SRT_HIP(t, hipEventRecord(t->ev_k1, t->stream));
+		SRT_HIP(t, hipEventRecord(t->ev_k[2 * b + 1], t->stream));
+		t->ev_k_used = 2 * (size_t)(b + 1);
 		rp.batch_samples = nbs;
 		rp.first_batch = (b == 0);
 		rp.last_batch = (b == n_batches - 1);
@@ -999,7 +1054,12 @@ int srt_last_trace_kernel_ms(srt_tracer *t, float *kernel_ms) {
 	SRT_HIP(t, hipSetDevice(t->device));
 	SRT_HIP(t, hipStreamSynchronize(t->stream));
 	*kernel_ms = 0.f;
-	if (t->have_kernel_ev) SRT_HIP(t, hipEventElapsedTime(kernel_ms, t->ev_k0, t->ev_k1));
+	if (t->have_kernel_ev)
+		for (size_t i = 0; i + 1 < t->ev_k_used; i += 2) { // one pair per sample batch: the reductions between them are not counted
+			float ms = 0.f;
+			SRT_HIP(t, hipEventElapsedTime(&ms, t->ev_k[i], t->ev_k[i + 1]));
+			*kernel_ms += ms;
+		}
 	return SRT_OK;
 }
 

@@ -18,7 +18,6 @@
 #include <string>
 #include <vector>
 
-#include "../host/helper.hpp"
 #include "../host/parser.hpp"
 #include "../host/tracer.hpp"
 
@@ -42,6 +41,22 @@ static std::vector<float> synthetic_sky(int w, int h) {
 		}
 	return out;
 }
+
+// The front-end's camera convention: camera_to_world carries the eye position in
+// column 3 and the yaw-then-pitch rotation in the upper 3x3.
+static glm::mat4 eye_matrix(const glm::vec3 &eye, float yaw, float pitch) {
+	return glm::translate(eye) * glm::eulerAngleYXZ(yaw, pitch, 0.0f);
+}
+
+// the scene's material table; the names only matter to a GUI, so the tool keeps none
+struct MaterialTable {
+	std::vector<Material> list;
+	int add(const Material &m) {
+		list.push_back(m);
+		return (int)list.size() - 1;
+	}
+	int size() const { return (int)list.size(); }
+};
 
 template <class T>
 static void dump(const std::string &path, const T *data, size_t count) {
@@ -87,17 +102,17 @@ int main(int argc, char **argv) {
 	// ---- scene construction, as src/main.cpp:95-126 does it ----
 	std::vector<Shape> shapes;
 	std::vector<Triangle> triangles;
-	MaterialHelper materials;
+	MaterialTable materials;
 	Box::create_triangle(triangles);
 
 	if (scene == "spheres") {
-		materials.push(Material(Color(0.8f, 0.8f, 0.9f)), "floor");
-		materials.push(Material(Color(0.9f, 0.3f, 0.3f)), "red wall");
-		materials.push(Material(Color(0.3f, 0.9f, 0.4f)), "green wall");
-		materials.push(Material(Color(0.9f, 0.95f, 1.0f)), "diffuse");
-		materials.push(Material(color::white, 1.0f, 0.0f, 0.0f, 1.0f, 1.5f), "glass");
-		materials.push(Material(Color(0.2f, 0.3f, 0.9f), 1.0f, 1.0f), "mirror");
-		materials.push(Material(color::white, 0.0f, 0.0f, 0.0f, 0.0f, 1.0f, Color(1.0f, 0.2f, 0.2f), 5.0f), "lamp");
+		materials.add(Material(Color(0.8f, 0.8f, 0.9f)));
+		materials.add(Material(Color(0.9f, 0.3f, 0.3f)));
+		materials.add(Material(Color(0.3f, 0.9f, 0.4f)));
+		materials.add(Material(Color(0.9f, 0.95f, 1.0f)));
+		materials.add(Material(color::white, 1.0f, 0.0f, 0.0f, 1.0f, 1.5f));
+		materials.add(Material(Color(0.2f, 0.3f, 0.9f), 1.0f, 1.0f));
+		materials.add(Material(color::white, 0.0f, 0.0f, 0.0f, 0.0f, 1.0f, Color(1.0f, 0.2f, 0.2f), 5.0f));
 		shapes.push_back(Shape(0, Plane({0, -1, 0}, {0, 1, 0})));
 		shapes.push_back(Shape(1, Plane({-4, 0, 0}, {1, 0, 0})));
 		shapes.push_back(Shape(2, Plane({0, 0, -6}, {0, 0, 1})));
@@ -106,13 +121,13 @@ int main(int argc, char **argv) {
 		shapes.push_back(Shape(5, Sphere({2.5f, 0.5f, -1.5f}, 1.0f)));
 		shapes.push_back(Shape(6, Sphere({0.6f, -1, 0}, 0.6f)));
 	} else if (scene == "meshes") {
-		materials.push(Material(Color(0.8f, 0.8f, 0.8f)), "floor");
-		materials.push(Material(Color(0.4f, 0.9f, 0.5f), 1.0f, 0.0f, 0.0f, 1.0f, 1.3f), "green glass");
-		materials.push(Material(Color(0.9f, 0.7f, 0.3f), 0.7f, 0.6f), "brass");
+		materials.add(Material(Color(0.8f, 0.8f, 0.8f)));
+		materials.add(Material(Color(0.4f, 0.9f, 0.5f), 1.0f, 0.0f, 0.0f, 1.0f, 1.3f));
+		materials.add(Material(Color(0.9f, 0.7f, 0.3f), 0.7f, 0.6f));
 		shapes.push_back(Shape(0, Plane({0, -1.2f, 0}, {0, 1, 0})));
 		shapes.push_back(Shape(2, Box::model({2.5f, -0.2f, -3.0f}, {2, 2, 2})));
 	} else {
-		materials.push(Material(), "Material0"); // the app's start-up state (main.cpp:100)
+		materials.add(Material()); // the app's start-up state (main.cpp:100)
 	}
 
 	int slot = 0;
@@ -126,19 +141,19 @@ int main(int argc, char **argv) {
 		m.transform = glm::translate(glm::vec3(-1.3f + 2.7f * (float)slot, 0.1f, -1.0f - 0.6f * (float)slot)) *
 		              glm::eulerAngleYXZ(0.6f - 1.5f * (float)slot, 0.2f, 0.0f);
 		m.compute_bounding_box(triangles);
-		shapes.push_back(Shape(materials.len() > 1 ? 1 + slot % (materials.len() - 1) : 0, m));
+		shapes.push_back(Shape(materials.size() > 1 ? 1 + slot % (materials.size() - 1) : 0, m));
 		slot++;
 		std::cout << path << ": " << pair->second << " triangles at " << pair->first << "\n";
 	};
 	for (auto &p : objs) add_model(load_obj_model(p, triangles), p);
 	for (auto &p : stls) add_model(load_stl_model(p, triangles), p);
 
-	Camera camera = {{0.0f, 0.5f, 5.0f}, 0.0f, 0.0f};
+	const glm::mat4 camera_to_world = eye_matrix(glm::vec3(0.0f, 0.5f, 5.0f), 0.0f, 0.0f);
 
 	if (!dump_prefix.empty()) {
 		dump(dump_prefix + ".shapes.bin", shapes.data(), shapes.size());
 		dump(dump_prefix + ".tris.bin", triangles.data(), triangles.size());
-		dump(dump_prefix + ".mats.bin", materials.materials.data(), materials.materials.size());
+		dump(dump_prefix + ".mats.bin", materials.list.data(), materials.list.size());
 	}
 	if (parse_only) return 0;
 
@@ -167,12 +182,12 @@ int main(int argc, char **argv) {
 	for (int frame = 0; frame < frames; frame++) {
 		if (time_not_moved == 1) {
 			tracer.clear_canvas();
-			tracer.update_scene(shapes, triangles, materials.materials);
+			tracer.update_scene(shapes, triangles, materials.list);
 		}
 		auto &options = tracer.options;
 		options.aspect_ratio = (float)width / (float)height;
 		options.fov_scale = 1.0f; // tan(90deg / 2)
-		options.camera_to_world = camera.camera_matrix();
+		options.camera_to_world = camera_to_world;
 		options.time = time_seed + 7919u * (unsigned)frame;
 		options.tick = (unsigned)frame;
 		tracer.render(time_not_moved, pixels);

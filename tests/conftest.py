@@ -16,6 +16,25 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def _hip_device_present():
+    try:
+        import torch
+        return torch.cuda.is_available()
+    except Exception:
+        return False
+
+
+def pytest_collection_modifyitems(config, items):
+    """A plain `pytest tests` on a box without a HIP device stays green: gpu-marked tests are skipped
+    there (the product itself never falls back: srt_create fails loudly, tests/test_abi_host.py)."""
+    if _hip_device_present():
+        return
+    skip = pytest.mark.skip(reason="no HIP device")
+    for item in items:
+        if "gpu" in item.keywords:
+            item.add_marker(skip)
+
+
 @pytest.fixture(scope="session")
 def sky():
     from simple_raytracer_amd import scenes

@@ -149,6 +149,13 @@ int srt_get_counters(srt_tracer *t, srt_counters *out);
  * (one extra VALU op per triangle test); results are unchanged. Default off. */
 int srt_set_count_triangles(srt_tracer *t, int enable);
 int srt_reset_counters(srt_tracer *t);
+/* Diagnostics of the trace kernel's scheduling (not part of any result): out[0..4] = rays, sky, paths,
+ * tri_tests, tri_pass_u as above; out[5] = paths that outlived their staging buffer and stored their
+ * radiance themselves, plus (staging buffers written out early << 40); out[6] = iterations of the
+ * waves' main loop; out[7] = SHADE phases executed (sums since the last srt_reset_counters); out[8] = persistent
+ * waves per CU and out[9] = workgroups of the most recent trace launch; out[10..17] = per-phase wave cycles
+ * (extend, sky ring, shade, park, deliver, refill, loop head, whole kernel) of a -DSRT_PHASE_CLOCK build, else 0. */
+int srt_debug_counters(srt_tracer *t, uint64_t out[18]);
 /* Device time of the most recent srt_trace (trace kernel(s) + ordered reduction) and of
  * the most recent resolve, from HIP events recorded on the handle's stream (milliseconds).
  * Synchronises the stream. */
@@ -188,9 +195,10 @@ int srt_partition_unpermute(const void *gathered, void *image, int height, int w
  * all 2^32 RNG outputs: out[0..2] = mismatch counts of the kernel-local sqrt / log / cos
  * specialisations against their generic definitions (must be 0); out[3..7] = sums of the
  * result bit patterns of detmath's log, cos, sqrt, atan2pi, pow on the device, to be
- * compared with the same sums from the host build of csrc/detmath.h; out[8..10] = mismatch
- * counts of the kernel's shared-reciprocal division, its normalize and its unguarded
- * Box-Muller square root against IEEE `/` and sqrt (must be 0); out[11] = mismatch count of the
+ * compared with the same sums from the host build of csrc/detmath.h; out[8], out[10] = mismatch
+ * counts of the kernel's shared-reciprocal division and its unguarded Box-Muller square root
+ * against IEEE `/` and sqrt (must be 0); out[9] = sum of the result bits of the built-in
+ * normalize (detmath's division-free rsqrt), again for comparison with the host build; out[11] = mismatch count of the
  * RNG-scaling shortcuts (log of the raw count, theta from the raw count) against the plain forms
  * (must be 0). */
 int srt_selftest_math(srt_tracer *t, uint32_t stride, uint64_t out[12]);

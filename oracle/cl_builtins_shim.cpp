@@ -39,12 +39,12 @@ static thread_local size_t g_gid[3];
 size_t get_global_id(uint d) { return d < 3 ? g_gid[d] : 0; }
 
 // ---- built-ins (C++ overloads mangle to the names the object imports) ---------
-float dot(float3 a, float3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
+float dot(float3 a, float3 b) { return dm_dot3(a.x, a.y, a.z, b.x, b.y, b.z); }
 float3 cross(float3 a, float3 b) {
 	float3 r;
-	r.x = a.y * b.z - a.z * b.y;
-	r.y = a.z * b.x - a.x * b.z;
-	r.z = a.x * b.y - a.y * b.x;
+	r.x = dm_cross1(a.y, b.z, a.z, b.y);
+	r.y = dm_cross1(a.z, b.x, a.x, b.z);
+	r.z = dm_cross1(a.x, b.y, a.y, b.x);
 	return r;
 }
 float sqrt(float x) { return dm_sqrtf(x); }
@@ -56,11 +56,12 @@ float3 sqrt(float3 v) {
 	return r;
 }
 float3 normalize(float3 v) {
-	float len = dm_sqrtf(dot(v, v));
+	float in[3] = {v.x, v.y, v.z}, out[3];
+	dm_normalize3(in, out);
 	float3 r;
-	r.x = v.x / len;
-	r.y = v.y / len;
-	r.z = v.z / len;
+	r.x = out[0];
+	r.y = out[1];
+	r.z = out[2];
 	return r;
 }
 float3 mix(float3 x, float3 y, float a) {
@@ -117,10 +118,10 @@ float4 shim_read_imagef(void *image, void *, float2 coord) {
 	const float *T11 = img->rgba + 4 * ((size_t)j1 * W + i1);
 	float w00 = (1.0f - a) * (1.0f - b), w10 = a * (1.0f - b), w01 = (1.0f - a) * b, w11 = a * b;
 	float4 r;
-	r.x = ((w00 * T00[0] + w10 * T10[0]) + w01 * T01[0]) + w11 * T11[0];
-	r.y = ((w00 * T00[1] + w10 * T10[1]) + w01 * T01[1]) + w11 * T11[1];
-	r.z = ((w00 * T00[2] + w10 * T10[2]) + w01 * T01[2]) + w11 * T11[2];
-	r.w = ((w00 * T00[3] + w10 * T10[3]) + w01 * T01[3]) + w11 * T11[3];
+	r.x = dm_bilinear(w00, T00[0], w10, T10[0], w01, T01[0], w11, T11[0]);
+	r.y = dm_bilinear(w00, T00[1], w10, T10[1], w01, T01[1], w11, T11[1]);
+	r.z = dm_bilinear(w00, T00[2], w10, T10[2], w01, T01[2], w11, T11[2]);
+	r.w = dm_bilinear(w00, T00[3], w10, T10[3], w01, T01[3], w11, T11[3]);
 	return r;
 }
 

@@ -62,13 +62,16 @@ static inline v3 vmul(v3 a, v3 b) { return V(a.x * b.x, a.y * b.y, a.z * b.z); }
 static inline v3 vscale(v3 a, float s) { return V(a.x * s, a.y * s, a.z * s); }
 static inline v3 vdivs(v3 a, float s) { return V(a.x / s, a.y / s, a.z / s); }
 static inline v3 vneg(v3 a) { return V(-a.x, -a.y, -a.z); }
-/* dot = (a.x*b.x + a.y*b.y) + a.z*b.z */
-static inline float vdot(v3 a, v3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
+/* the built-ins dot, cross, normalize, mix as detmath.h pins them (FMA forms) */
+static inline float vdot(v3 a, v3 b) { return dm_dot3(a.x, a.y, a.z, b.x, b.y, b.z); }
 static inline v3 vcross(v3 a, v3 b) {
-	return V(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+	return V(dm_cross1(a.y, b.z, a.z, b.y), dm_cross1(a.z, b.x, a.x, b.z), dm_cross1(a.x, b.y, a.y, b.x));
 }
-/* normalize(v) = v / sqrt(dot(v,v)), per-component true division */
-static inline v3 vnormalize(v3 a) { return vdivs(a, dm_sqrtf(vdot(a, a))); }
+static inline v3 vnormalize(v3 a) {
+	float v[3] = {a.x, a.y, a.z};
+	dm_normalize3(v, v);
+	return V(v[0], v[1], v[2]);
+}
 static inline v3 vmix(v3 x, v3 y, float a) {
 	return V(dm_mix(x.x, y.x, a), dm_mix(x.y, y.y, a), dm_mix(x.z, y.z, a));
 }
@@ -313,9 +316,9 @@ static v3 sample_sky(const scene_t *scene, float s, float t) {
 	const float *T11 = scene->sky + 4 * ((size_t)j1 * W + i1);
 	float w00 = (1.0f - a) * (1.0f - b), w10 = a * (1.0f - b), w01 = (1.0f - a) * b, w11 = a * b;
 	v3 r;
-	r.x = ((w00 * T00[0] + w10 * T10[0]) + w01 * T01[0]) + w11 * T11[0];
-	r.y = ((w00 * T00[1] + w10 * T10[1]) + w01 * T01[1]) + w11 * T11[1];
-	r.z = ((w00 * T00[2] + w10 * T10[2]) + w01 * T01[2]) + w11 * T11[2];
+	r.x = dm_bilinear(w00, T00[0], w10, T10[0], w01, T01[0], w11, T11[0]);
+	r.y = dm_bilinear(w00, T00[1], w10, T10[1], w01, T01[1], w11, T11[1]);
+	r.z = dm_bilinear(w00, T00[2], w10, T10[2], w01, T01[2], w11, T11[2]);
 	return r;
 }
 
@@ -546,9 +549,9 @@ int orc_num_counters(void) { return ORC_C_COUNT; }
  * patterns of detmath over r = 0, stride, ... ; out[3..7] as in include/srt_abi.h. */
 static inline uint64_t canon_bits(float a) { return (a != a) ? 0x7fc00000ull : (uint64_t)dm_f2u(a); }
 void orc_math_checksums(uint32_t stride, uint64_t *out8) {
-	uint64_t s_log = 0, s_cos = 0, s_sqrt = 0, s_atan = 0, s_pow = 0;
+	uint64_t s_log = 0, s_cos = 0, s_sqrt = 0, s_atan = 0, s_pow = 0, s_norm = 0;
 	const uint64_t total = (0x100000000ull + stride - 1) / stride;
-#pragma omp parallel for reduction(+ : s_log, s_cos, s_sqrt, s_atan, s_pow) schedule(static)
+#pragma omp parallel for reduction(+ : s_log, s_cos, s_sqrt, s_atan, s_pow, s_norm) schedule(static)
 	for (uint64_t i = 0; i < total; i++) {
 		const uint32_t r = (uint32_t)(i * stride);
 		const float u = (float)r / 4294967296.0f;
@@ -558,8 +561,11 @@ void orc_math_checksums(uint32_t stride, uint64_t *out8) {
 		s_sqrt += canon_bits(dm_sqrtf(u));
 		s_atan += canon_bits(dm_atan2pif(u - 0.5f, 0.37f - u));
 		s_pow += canon_bits(dm_powf(u, 25.0f));
+		const v3 nv = vnormalize(V(u - 0.5f, 0.37f - u, (float)(r & 0xffffu) * 1e-3f - 30.0f));
+		s_norm += canon_bits(nv.x) + canon_bits(nv.y) + canon_bits(nv.z);
 	}
 	for (int k = 0; k < 8; k++) out8[k] = 0;
+	out8[0] = s_norm; /* compared with out[9] of the device self-test */
 	out8[3] = s_log;
 	out8[4] = s_cos;
 	out8[5] = s_sqrt;

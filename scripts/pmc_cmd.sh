@@ -1,0 +1,41 @@
+#!/bin/bash
+# usage: scripts/pmc_cmd.sh <tag> <group,group,...> <python script + args...>   (run on the GPU box via gpurun)
+# One rocprofv3 --pmc pass per counter group (never combined with tracing other than --kernel-trace); prints and
+# saves per-launch averages of every counter for the srt_* kernels into gpurun_out/pmc_<tag>/summary.json.
+set -u
+TAG=$1; GROUPS_=$2; shift 2
+R=$PWD
+OUT=$R/gpurun_out/pmc_$TAG
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+declare -A G
+G[sq1]="SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU"
+G[sq2]="SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_SCA SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INST_CYCLES_SALU SQ_ACTIVE_INST_MISC"
+G[mix]="SQ_INSTS_VALU SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_CVT SQ_INSTS_VALU_FMA_F64"
+G[flow]="SQ_INSTS_BRANCH SQ_IFETCH SQ_IFETCH_LEVEL SQ_INST_LEVEL_SMEM SQ_INST_LEVEL_LDS SQ_INSTS_LDS SQ_WAIT_INST_LDS SQ_INSTS_SMEM"
+G[cache]="SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES SQC_DCACHE_REQ SQC_DCACHE_HITS SQC_DCACHE_MISSES SQC_TC_STALL SQ_LDS_BANK_CONFLICT"
+G[lds]="SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_ADDR_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INST_LEVEL_LDS SQ_LDS_UNALIGNED_STALL"
+G[fetch]="FETCH_SIZE"
+G[write]="WRITE_SIZE"
+G[grbm]="GRBM_GUI_ACTIVE GRBM_COUNT"
+for name in ${GROUPS_//,/ }; do
+  rocprofv3 --kernel-trace --pmc ${G[$name]} --output-format csv -d $OUT/$name -- python3 "$R/$1" "${@:2}" > $OUT/$name.log 2>&1
+  echo "$name rc=$?"
+done
+python3 - <<PY
+import csv, glob, collections, json
+res = collections.defaultdict(dict)
+for f in glob.glob("$OUT/**/*counter_collection.csv", recursive=True):
+    agg = collections.defaultdict(lambda: collections.defaultdict(lambda: [0.0, 0]))
+    for row in csv.DictReader(open(f)):
+        kn = row["Kernel_Name"].split("(")[0]
+        if "srt_" not in kn: continue
+        a = agg[kn][row["Counter_Name"]]; a[0] += float(row["Counter_Value"]); a[1] += 1
+    for kn, d in agg.items():
+        for k, (s, n) in d.items():
+            res[kn][k] = s / n
+            res[kn]["launches"] = n
+json.dump(res, open("$OUT/summary.json", "w"), indent=1, sort_keys=True)
+for kn, d in res.items():
+    if "trace" in kn: print(kn, json.dumps(d, sort_keys=True))
+PY

@@ -8,11 +8,22 @@
  * pow <=16, atan2pi <=6 ulp; + - * exact IEEE). A path tracer is chaotic: a 1-ulp
  * difference flips a hit/miss or a `material->x > random_float()` branch, so parity
  * "within 1e-4 per pixel" is only reachable when every realisation of the kernel
- * uses the SAME rounding everywhere. detmath pins one realisation that uses nothing
- * but IEEE-754 correctly rounded + - * / sqrt, conversions and integer ops, so the
- * x86-64 build (gcc/clang, -ffp-contract=off) and the gfx950 build (hipcc,
- * -ffp-contract=off, default correctly-rounded f32 divide/sqrt, f32 denormals on)
+ * uses the SAME rounding everywhere. detmath pins one realisation built from nothing
+ * but IEEE-754 correctly rounded + - * / sqrt, fused multiply-add (fmaf: one rounding,
+ * fully specified by IEEE-754, a single instruction on gfx950 and on every x86-64 since
+ * Haswell / Zen), conversions and integer ops, so the x86-64 build (gcc/clang) and the
+ * gfx950 build (hipcc, default correctly-rounded f32 divide/sqrt, f32 denormals on)
  * produce identical bits. tests/test_detmath.py checks the ULP bounds against libm.
+ *
+ * Revision 2 (round 2): the built-ins are written the way a GPU's OpenCL library
+ * writes them -- dot / cross / mix and the polynomial kernels of cos / log / atan2pi
+ * as FMA chains, normalize as v * rsqrt(dot(v, v)) with a division-free Newton rsqrt --
+ * because on gfx950 they are most of the trace kernel's instructions (DESIGN.md
+ * "Numerics"). The OpenCL bounds they have to meet: dot / cross / mix: at least as
+ * accurate as the unfused forms; normalize <= 2 + n ulp per component (n = 3);
+ * cos <= 4, log <= 3, atan2pi <= 6, pow <= 16 ulp. Fused operations appear ONLY
+ * where written as dm_fmaf: everything else, including every expression of the
+ * reference kernel itself, stays unfused (-ffp-contract=off).
  *
  * Every file that includes this header MUST be compiled with -ffp-contract=off.
  * Polynomial coefficients: simple-raytracer_amd/tools/gen_detmath_coeffs.py.
@@ -74,40 +85,61 @@ DM_FN float dm_sign(float x) {
 	if (x == 0.0f) return x;
 	return 0.0f;
 }
-/* mix(x, y, a) = x + (y - x) * a */
-DM_FN float dm_mix(float x, float y, float a) { return x + (y - x) * a; }
+/* The one fused operation: a * b + c with a single rounding (IEEE-754 fusedMultiplyAdd). */
+DM_FN float dm_fmaf(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+/* mix(x, y, a) = x + (y - x) * a, the product and sum fused */
+DM_FN float dm_mix(float x, float y, float a) { return dm_fmaf(y - x, a, x); }
+/* dot(a, b) = fma(a.z, b.z, fma(a.y, b.y, a.x * b.x)) */
+DM_FN float dm_dot3(float ax, float ay, float az, float bx, float by, float bz) { return dm_fmaf(az, bz, dm_fmaf(ay, by, ax * bx)); }
+/* one component of cross(a, b): p * q - r * t as fma(p, q, -(r * t)) */
+DM_FN float dm_cross1(float p, float q, float r, float t) { return dm_fmaf(p, q, -(r * t)); }
+/* 1 / sqrt(d) without a division or a square root: the classic exponent-halving first guess (3.4 % off) and three
+ * Newton steps y <- y + y (0.5 - (0.5 d y) y), each two FMAs / products and one FMA; the last one is written in the
+ * correction form, which leaves ~1 ulp for normal d > 0. The products are ordered so that d = 0 stays finite (a large
+ * value: normalize(0) = 0, as OpenCL specifies); d = inf or NaN does not give a number. */
+DM_FN float dm_rsqrtf(float d) {
+	float y = dm_u2f(0x5f375a86u - (dm_f2u(d) >> 1));
+	const float h = 0.5f * d;
+	y = y * dm_fmaf(-(h * y), y, 1.5f);
+	y = y * dm_fmaf(-(h * y), y, 1.5f);
+	y = dm_fmaf(y, dm_fmaf(-(h * y), y, 0.5f), y);
+	return y;
+}
+/* normalize(v) = v * rsqrt(dot(v, v)); out may alias v */
+DM_FN void dm_normalize3(const float v[3], float out[3]) {
+	const float r = dm_rsqrtf(dm_dot3(v[0], v[1], v[2], v[0], v[1], v[2]));
+	out[0] = v[0] * r, out[1] = v[1] * r, out[2] = v[2] * r;
+}
 /* sqrt is IEEE correctly rounded on both targets. */
 DM_FN float dm_sqrtf(float x) { return DM_SQRTF(x); }
 
-/* ---- cos(x): accurate for |x| <= ~8 (the kernel feeds [0, 2*pi]) ----------- */
-/* Cody-Waite reduction by pi/2 split into 11+11+11 bit chunks + float tail, so
- * k*C1..k*C3 are exact for k < 2^13; then degree-3-in-z tails for sin and cos. */
+/* ---- cos(x): accurate for |x| <= 16384 (the kernel feeds [0, 2*pi]) --------- */
+/* Cody-Waite reduction by pi/2 = C1 + C2 + C3 (three floats, 72 bits) with one FMA per
+ * part, then degree-2-in-z tails for sin and cos evaluated as FMA chains. */
 DM_FN float dm_cosf(float x) {
 	const float TWO_OVER_PI = 6.36619747e-01f;
-	const float C1 = 1.5703125f;                /* 0x3fc90000 */
-	const float C2 = 4.83751297e-04f;           /* 0x39fda000 */
-	const float C3 = 7.54953362e-08f;           /* 0x33a22000 */
-	const float C4 = 2.56334407e-12f;           /* 0x2c34611a */
+	const float C1 = 1.570796371e+00f;          /* 0x3fc90fdb = float(pi/2) */
+	const float C2 = -4.371138829e-08f;         /* 0xb33bbd2e = float(pi/2 - C1) */
+	const float C3 = -1.715124510e-15f;         /* 0xa6f72ced */
 	float ax = dm_fabs(x);
 	if (!(ax < 16384.0f)) {
 		/* out of the supported range (or NaN/inf): NaN for non-finite, else best effort */
 		if (!(ax < DM_INF_F)) return DM_NAN_F;
 	}
-	int k = (int)(ax * TWO_OVER_PI + 0.5f);
+	int k = (int)dm_fmaf(ax, TWO_OVER_PI, 0.5f);
 	float fk = (float)k;
-	float r = ax - fk * C1;
-	r = r - fk * C2;
-	r = r - fk * C3;
-	r = r - fk * C4;
+	float r = dm_fmaf(-fk, C1, ax);
+	r = dm_fmaf(-fk, C2, r);
+	r = dm_fmaf(-fk, C3, r);
 	float z = r * r;
 	int odd = k & 1;
 	/* coefficients: sin tail (odd quadrants) or cos tail (even quadrants) */
 	float c0 = odd ? -1.66666642e-01f : 4.16666642e-02f;
 	float c1 = odd ? 8.33272468e-03f : -1.38882792e-03f;
 	float c2 = odd ? -1.95828557e-04f : 2.45428964e-05f;
-	float p = c0 + z * (c1 + z * c2);
-	float s_res = r + (r * z) * p;                       /* sin(r) */
-	float c_res = ((z * z) * p - 0.5f * z) + 1.0f;       /* cos(r) */
+	float p = dm_fmaf(z, dm_fmaf(z, c2, c1), c0);
+	float s_res = dm_fmaf(r * z, p, r);                              /* sin(r) */
+	float c_res = dm_fmaf(z * z, p, dm_fmaf(-0.5f, z, 1.0f));        /* cos(r) */
 	float res = odd ? s_res : c_res;
 	/* cos(x): k&3 = 0: cos r, 1: -sin r, 2: -cos r, 3: sin r */
 	int neg = ((k + 1) >> 1) & 1;
@@ -141,10 +173,10 @@ DM_FN float dm_logf(float x) {
 	float f = x - 1.0f;
 	float s = f / (2.0f + f);
 	float z = s * s;
-	float R = z * (L0 + z * (L1 + z * (L2 + z * L3)));
+	float R = z * dm_fmaf(z, dm_fmaf(z, dm_fmaf(z, L3, L2), L1), L0);
 	float hfsq = (0.5f * f) * f;
 	float dk = (float)k;
-	return dk * LN2_HI + (f - (hfsq - (s * (hfsq + R) + dk * LN2_LO)));
+	return dm_fmaf(dk, LN2_HI, f - (hfsq - dm_fmaf(s, hfsq + R, dk * LN2_LO)));
 }
 
 /* ---- double-precision helpers for pow / atan2pi (once per escaping path) --- */
@@ -299,7 +331,7 @@ DM_FN double dm_pown_d(double x, int n) {
 
 /* atan2pi(y, x) = atan2(y, x) / pi, OpenCL C 7.5.1 edge cases. Float only:
  * a = min/max in [0,1] (one IEEE division), atan(a)/pi = a * P(a^2) with a degree-9
- * near-minimax P (tools/gen_detmath_coeffs.py), then exact-constant quadrant folds
+ * near-minimax P (tools/gen_detmath_coeffs.py; FMA Horner), then exact-constant quadrant folds
  * 0.5 - t and 1 - t. Measured max error < 3 ulp against libm (bound: 6). */
 DM_FN float dm_atan2pif(float y, float x) {
 	if (x != x || y != y) return DM_NAN_F;
@@ -320,21 +352,26 @@ DM_FN float dm_atan2pif(float y, float x) {
 		float a = mn / mx;
 		float z = a * a;
 		float p = -5.414992338e-04f;
-		p = p * z + 3.338322509e-03f;
-		p = p * z + -9.661298245e-03f;
-		p = p * z + 1.817217097e-02f;
-		p = p * z + -2.657799982e-02f;
-		p = p * z + 3.479872271e-02f;
-		p = p * z + -4.539104179e-02f;
-		p = p * z + 6.365585327e-02f;
-		p = p * z + -1.061031148e-01f;
-		p = p * z + 3.183098733e-01f;
+		p = dm_fmaf(p, z, 3.338322509e-03f);
+		p = dm_fmaf(p, z, -9.661298245e-03f);
+		p = dm_fmaf(p, z, 1.817217097e-02f);
+		p = dm_fmaf(p, z, -2.657799982e-02f);
+		p = dm_fmaf(p, z, 3.479872271e-02f);
+		p = dm_fmaf(p, z, -4.539104179e-02f);
+		p = dm_fmaf(p, z, 6.365585327e-02f);
+		p = dm_fmaf(p, z, -1.061031148e-01f);
+		p = dm_fmaf(p, z, 3.183098733e-01f);
 		float t = a * p;
 		if (swap) t = 0.5f - t;
 		if (sx) t = 1.0f - t;
 		r = t;
 	}
 	return sy ? -r : r;
+}
+
+/* One channel of the LINEAR image filter (OpenCL 3.0 8.2): w00 T00 + w10 T10 + w01 T01 + w11 T11 as an FMA chain. */
+DM_FN float dm_bilinear(float w00, float t00, float w10, float t10, float w01, float t01, float w11, float t11) {
+	return dm_fmaf(w11, t11, dm_fmaf(w01, t01, dm_fmaf(w10, t10, w00 * t00)));
 }
 
 #endif /* SRT_DETMATH_H */

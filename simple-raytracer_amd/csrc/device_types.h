@@ -9,14 +9,15 @@
 
 /* Scene data for the wave-uniform intersection loop. Every lane of a wave tests the SAME
  * shape at the same time (array order, render.cl:299), so these records are fetched with
- * scalar loads into SGPRs, not staged per lane. Consecutive shapes of one type form a RUN; the
- * kernel walks runs in array order (so the first-of-equal-t rule of render.cl:306 is
- * kept) and, inside a run, reads homogeneous packed records with wide scalar loads:
- *   sphere: 4 dwords  {cx, cy, cz, r*r}                    -> 4 spheres per s_load_dwordx16
- *   plane : 8 dwords  {px, py, pz, 0, nx, ny, nz, 0}       -> 2 planes per s_load_dwordx16
- *   model : 8 dwords  {min.x, min.y, min.z, first_wtri(bits), max.x, max.y, max.z, count(bits)}
+ * scalar loads into SGPRs, not staged per lane. Consecutive shapes of one type are packed into
+ * 64-byte BLOCKS, walked in array order (so the first-of-equal-t rule of render.cl:306 is kept);
+ * block b lives at dword 16 * b of the packed array and has a 16-byte header (ShapeRun) in a
+ * parallel array, so the kernel can fetch header and data of block b + 1 while it tests block b:
+ *   sphere: 4 dwords  {cx, cy, cz, r*r}                    -> 4 spheres per block
+ *   plane : 8 dwords  {px, py, pz, 0, nx, ny, nz, 0}       -> 2 planes per block
+ *   model : 8 dwords  {min.x, min.y, min.z, first_wtri(bits), max.x, max.y, max.z, count(bits)} -> 2 per block
  *           (with a BVH: the root node's index in place of first_wtri)
- * data_off is in dwords into the packed array and is a multiple of 16 (64 B). */
+ * A block that is not full ends in records that cannot be hit (srt_abi.hip). */
 struct ShapeRun {
 	int32_t type;
 	uint32_t first_shape;
@@ -62,7 +63,7 @@ typedef srt_bvh_node BvhNode; /* include/srt_types.h */
  * summed on the host when asked for: thousands of waves ending together on three shared atomics
  * cost a small dispatch 100 us (profiles/README.md). Launches of a handle are stream-ordered and a
  * launch has one wave per index, so a plain read-modify-write is enough. */
-#define SRT_WAVE_CTR_STRIDE 8 /* unsigned long long per wave: rays, sky, paths, tri, tri_pass_u, 3 spare */
+#define SRT_WAVE_CTR_STRIDE 16 /* unsigned long long per wave: rays, sky, paths, tri, tri_pass_u, 3 diagnostics, 8 phase clocks (-DSRT_PHASE_CLOCK builds) */
 #define SRT_WAVE_CTR_SLOTS 8192 /* >= CUs * 4 SIMDs * 8 waves */
 
 enum { SRT_CTR_RAYS = 0, SRT_CTR_SKY, SRT_CTR_TRI, SRT_CTR_TRI_PASS_U, SRT_CTR_NAN, SRT_CTR_PATHS, SRT_CTR_QUEUE, SRT_CTR_WATCHDOG, SRT_CTR_COUNT };
@@ -139,6 +140,7 @@ struct ResolveParams {
 void srt_launch_trace(TraceParams p, bool count_triangles, int num_waves, void *stream);
 void srt_launch_reduce(const ReduceParams &p, void *stream);
 int srt_trace_waves_per_simd(int has_models, int use_bvh);
+int srt_trace_resident_waves_per_cu(const TraceParams &p, bool count_triangles); /* from the runtime's occupancy calculator */
 int srt_sub_job_items(int has_models, int use_bvh); /* items per LDS-staged sub-job; chunks per atomic are multiples of it */
 void srt_launch_prepass(const PrepassParams &p, uint64_t total_wtris, void *stream);
 void srt_launch_resolve(const ResolveParams &p, void *stream);

@@ -49,10 +49,10 @@ __device__ __forceinline__ f3 operator*(f3 a, f3 b) { return mk(a.x * b.x, a.y *
 __device__ __forceinline__ f3 operator*(f3 a, float s) { return mk(a.x * s, a.y * s, a.z * s); }
 __device__ __forceinline__ f3 operator/(f3 a, float s) { return mk(a.x / s, a.y / s, a.z / s); }
 __device__ __forceinline__ f3 neg(f3 a) { return mk(-a.x, -a.y, -a.z); }
-// dot = (a.x*b.x + a.y*b.y) + a.z*b.z  (pinned)
-__device__ __forceinline__ float dot3(f3 a, f3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
+// the OpenCL built-ins dot and cross as detmath.h pins them (FMA forms: 3 and 6 instructions)
+__device__ __forceinline__ float dot3(f3 a, f3 b) { return dm_dot3(a.x, a.y, a.z, b.x, b.y, b.z); }
 __device__ __forceinline__ f3 cross3(f3 a, f3 b) {
-	return mk(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+	return mk(dm_cross1(a.y, b.z, a.z, b.y), dm_cross1(a.z, b.x, a.x, b.z), dm_cross1(a.x, b.y, a.y, b.x));
 }
 // Correctly rounded sqrt. hipcc's own expansion (v_sqrt_f32 + two FMA residual tests
 // against the neighbouring floats) spends 7 more instructions on 2^32 pre/post scaling
@@ -136,20 +136,11 @@ __device__ __forceinline__ f3 div3(f3 a, float b) {
 #endif
 	return a / b;
 }
-// a / sqrt(dot(a, a)); 2^-80 <= d <= 2^80 puts the length in [2^-40, 2^40] and lets the
-// square root skip its own small-argument guard. No component exceeds the length by more
-// than rounding, so only the smallest one needs a look.
+// the built-in normalize: a * rsqrt(dot(a, a)) with detmath.h's division-free rsqrt -- 15 plain instructions, no
+// transcendental, no guard (before: IEEE sqrt and three IEEE quotients behind a range check)
 __device__ __forceinline__ f3 normalize3(f3 a) {
-	const float d = dot3(a, a);
-#ifndef SRT_NO_FAST_DIV
-	const float mn = __builtin_fminf(__builtin_fminf(dm_fabs(a.x), dm_fabs(a.y)), dm_fabs(a.z));
-	if (__builtin_expect(mn >= 0x1p-60f && d >= 0x1p-80f && d <= 0x1p80f, 1)) {
-		const float b = sqrt_core(d);
-		const float r = rcp_refined(b);
-		return mk(div_core(a.x, b, r), div_core(a.y, b, r), div_core(a.z, b, r));
-	}
-#endif
-	return a / sqrt_ieee(d);
+	const float r = dm_rsqrtf(dot3(a, a));
+	return mk(a.x * r, a.y * r, a.z * r);
 }
 __device__ __forceinline__ f3 mix3(f3 x, f3 y, float a) {
 	return mk(dm_mix(x.x, y.x, a), dm_mix(x.y, y.y, a), dm_mix(x.z, y.z, a));
@@ -206,10 +197,10 @@ __device__ __forceinline__ float log_unit_biased(float u) {
 	float s = f / den;
 #endif
 	float z = s * s;
-	float R = z * (L0 + z * (L1 + z * (L2 + z * L3)));
+	float R = z * dm_fmaf(z, dm_fmaf(z, dm_fmaf(z, L3, L2), L1), L0);
 	float hfsq = (0.5f * f) * f;
 	float dk = (float)k;
-	float r = dk * LN2_HI + (f - (hfsq - (s * (hfsq + R) + dk * LN2_LO)));
+	float r = dm_fmaf(dk, LN2_HI, f - (hfsq - dm_fmaf(s, hfsq + R, dk * LN2_LO)));
 	// Keep the zero test a select: left alone, the compiler sinks the whole polynomial into a branch
 	// on u != 0, which also keeps the three logarithms of a bounce from being scheduled together.
 	asm volatile("" : "+v"(r));
@@ -220,20 +211,19 @@ __device__ __forceinline__ float log_count(float c) { return log_unit_biased<159
 
 // dm_cosf restricted to finite x in [0, 8): detmath.h's range / NaN guard dropped.
 __device__ __forceinline__ float cos_2pi(float x) {
-	int k = (int)(x * 6.36619747e-01f + 0.5f);
+	int k = (int)dm_fmaf(x, 6.36619747e-01f, 0.5f);
 	float fk = (float)k;
-	float r = x - fk * 1.5703125f;
-	r = r - fk * 4.83751297e-04f;
-	r = r - fk * 7.54953362e-08f;
-	r = r - fk * 2.56334407e-12f;
+	float r = dm_fmaf(-fk, 1.570796371e+00f, x);
+	r = dm_fmaf(-fk, -4.371138829e-08f, r);
+	r = dm_fmaf(-fk, -1.715124510e-15f, r);
 	float z = r * r;
 	int odd = k & 1;
 	float c0 = odd ? -1.66666642e-01f : 4.16666642e-02f;
 	float c1 = odd ? 8.33272468e-03f : -1.38882792e-03f;
 	float c2 = odd ? -1.95828557e-04f : 2.45428964e-05f;
-	float p = c0 + z * (c1 + z * c2);
-	float s_res = r + (r * z) * p;
-	float c_res = ((z * z) * p - 0.5f * z) + 1.0f;
+	float p = dm_fmaf(z, dm_fmaf(z, c2, c1), c0);
+	float s_res = dm_fmaf(r * z, p, r);
+	float c_res = dm_fmaf(z * z, p, dm_fmaf(-0.5f, z, 1.0f));
 	float res = odd ? s_res : c_res;
 	return (((k + 1) >> 1) & 1) ? -res : res;
 }
@@ -291,32 +281,60 @@ __device__ __forceinline__ Tri2 ld_tri2(const float *p) {
 
 __device__ __forceinline__ uint32_t f2u(float f) { return __float_as_uint(f); }
 
-// render.cl:180-204 against one sphere held in SGPRs; updates the lane's closest hit
-__device__ __forceinline__ void test_sphere(float cx, float cy, float cz, float r2, f3 org, f3 dir, int idx, float &tmin, int &best) {
-	f3 L = mk(cx - org.x, cy - org.y, cz - org.z);
-	float b = dot3(L, dir);
-	float c = dot3(L, L) - r2;
-	float disc = b * b - c;
-	float sq = sqrt_ieee(disc);
-	float t = b - sq;
-	if (t < 0.0f) t = b + sq;
-	bool hit = !(disc < 0.0f) && !(t < 0.0f);
-	if (hit && t < tmin) {
-		tmin = t;
-		best = idx;
+// render.cl:180-204 against FOUR spheres held in SGPRs (one 64-byte block {cx, cy, cz, r*r} x 4; the host fills a
+// run's last block with spheres of r*r = -inf, whose discriminant is -inf or NaN: never a hit). Straight-line:
+// the four tests are independent chains the scheduler can interleave, and the four square roots share ONE
+// small-argument guard (sqrt_ieee above) instead of a branch each. Updates the lane's closest hit in array order.
+__device__ __forceinline__ void test_spheres4(const Blk16 &s, f3 org, f3 dir, int idx0, float &tmin, int &best) {
+	float bq[4], disc[4], sq[4];
+	bool tiny = false;
+#pragma unroll
+	for (int i = 0; i < 4; i++) {
+		f3 L = mk(s.v[4 * i] - org.x, s.v[4 * i + 1] - org.y, s.v[4 * i + 2] - org.z);
+		bq[i] = dot3(L, dir);
+		float c = dot3(L, L) - s.v[4 * i + 3];
+		disc[i] = bq[i] * bq[i] - c;
+#ifndef SRT_NO_FAST_SQRT
+		tiny = tiny || ((dm_f2u(disc[i]) & 0x7fffffffu) - 1u) < 0x0f7fffffu; // 0 < |x| < 2^-96
+#endif
+	}
+#ifndef SRT_NO_FAST_SQRT
+	if (__builtin_expect(tiny, 0)) {
+#pragma unroll
+		for (int i = 0; i < 4; i++) sq[i] = __builtin_sqrtf(disc[i]);
+	} else {
+#pragma unroll
+		for (int i = 0; i < 4; i++) sq[i] = sqrt_core(disc[i]);
+	}
+#else
+#pragma unroll
+	for (int i = 0; i < 4; i++) sq[i] = dm_sqrtf(disc[i]);
+#endif
+#pragma unroll
+	for (int i = 0; i < 4; i++) {
+		float t = bq[i] - sq[i];
+		if (t < 0.0f) t = bq[i] + sq[i];
+		bool hit = !(disc[i] < 0.0f) && !(t < 0.0f);
+		if (hit && t < tmin) {
+			tmin = t;
+			best = idx0 + i;
+		}
 	}
 }
 
-// render.cl:206-221
-__device__ __forceinline__ void test_plane(float px, float py, float pz, float nx, float ny, float nz, f3 org, f3 dir, int idx, float &tmin,
-                                           int &best) {
-	f3 n = mk(nx, ny, nz);
-	float denom = dot3(n, dir);
-	float t = dot3(n, mk(px - org.x, py - org.y, pz - org.z)) / denom;
-	bool hit = !(dm_fabs(denom) == 0.0f) && !(t < 0.0f);
-	if (hit && t < tmin) {
-		tmin = t;
-		best = idx;
+// render.cl:206-221 against TWO planes (one 64-byte block {p, 0, n, 0} x 2; a run's last block is filled with a
+// plane of normal 0: denom == 0, never a hit)
+__device__ __forceinline__ void test_planes2(const Blk16 &b, f3 org, f3 dir, int idx0, float &tmin, int &best) {
+#pragma unroll
+	for (int i = 0; i < 2; i++) {
+		f3 n = mk(b.v[8 * i + 4], b.v[8 * i + 5], b.v[8 * i + 6]);
+		float denom = dot3(n, dir);
+		float t = dot3(n, mk(b.v[8 * i] - org.x, b.v[8 * i + 1] - org.y, b.v[8 * i + 2] - org.z)) / denom;
+		bool hit = !(dm_fabs(denom) == 0.0f) && !(t < 0.0f);
+		if (hit && t < tmin) {
+			tmin = t;
+			best = idx0 + i;
+		}
 	}
 }
 
@@ -492,9 +510,8 @@ __device__ __forceinline__ f3 sample_sky(const float *__restrict__ sky, int W, i
 	float4 T01 = img[(size_t)j1 * W + i0];
 	float4 T11 = img[(size_t)j1 * W + i1];
 	float w00 = (1.0f - a) * (1.0f - b), w10 = a * (1.0f - b), w01 = (1.0f - a) * b, w11 = a * b;
-	return mk(((w00 * T00.x + w10 * T10.x) + w01 * T01.x) + w11 * T11.x,
-	          ((w00 * T00.y + w10 * T10.y) + w01 * T01.y) + w11 * T11.y,
-	          ((w00 * T00.z + w10 * T10.z) + w01 * T01.z) + w11 * T11.z);
+	return mk(dm_bilinear(w00, T00.x, w10, T10.x, w01, T01.x, w11, T11.x), dm_bilinear(w00, T00.y, w10, T10.y, w01, T01.y, w11, T11.y),
+	          dm_bilinear(w00, T00.z, w10, T10.z, w01, T01.z, w11, T11.z));
 }
 
 // render.cl:380-394
@@ -514,99 +531,148 @@ __device__ __forceinline__ f3 sky_box(const TraceParams &p, f3 dir) {
 	return sample_sky(p.sky, p.sky_w, p.sky_h, p.f_sky_w, p.f_sky_h, u, v) + sun;
 }
 
-// Evaluate the sky for the first n queued escapes (n <= 64), one per lane, and finish their
-// paths: mask *= sky; color += mask (render.cl:464-465); the radiance goes to the path's
-// staging slot. Called with all 64 lanes in wave-uniform control flow.
-__device__ __forceinline__ void resolve_ring(const TraceParams &p, const float *__restrict__ ring, uint32_t n, float4 *__restrict__ stage, int lane) {
-	asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // one-wave workgroup: LDS ops are in order; stop compiler motion only
-	if ((uint32_t)lane < n) {
-		const f3 d = mk(ring[0 * 64 + lane], ring[1 * 64 + lane], ring[2 * 64 + lane]);
-		f3 m = mk(ring[3 * 64 + lane], ring[4 * 64 + lane], ring[5 * 64 + lane]);
-		f3 c = mk(ring[6 * 64 + lane], ring[7 * 64 + lane], ring[8 * 64 + lane]);
-		const uint32_t dest = dm_f2u(ring[9 * 64 + lane]);
-		m = m * sky_box(p, d);
-		c = c + m;
-		stage[dest] = make_float4(c.x, c.y, c.z, 0.f);
-	}
-	asm volatile("" ::: "memory");
-}
 
 } // namespace
 
 // ---------------------------------------------------------------------------------
 // Trace kernel. 64-thread workgroups = one persistent wave pulling (pixel, sample) items.
 // ---------------------------------------------------------------------------------
-// Items per LDS-staged sub-job (two 16-byte-slot buffers per wave, next to the 2.5 KB sky
-// ring). A/B on MI355X: the sphere/plane kernel runs 20 waves per CU and is fastest with
-// 2 x 128 x 16 B = 4 KB (192: -6 %, LDS then limits residency); the mesh kernels run 16 waves
-// per CU and prefer the longer window of 256 (their paths are long: with fewer slots idle
-// lanes wait more often for the older buffer).
+// The wave alternates between TWO phases that each run on (nearly) all 64 lanes:
+//   EXTEND  closest_intersection for every lane that holds a ray;
+//   SHADE   the bounce of 64 paths that hit something.
+// Rays that escape go to the sky ring (resolved 64 at a time). Rays that hit are shaded
+// at once when, together with the paths waiting in the wave's LDS hit queue, they fill
+// the wave; the lanes freed by escapes take waiting paths from the queue. Otherwise the hits
+// are PARKED in the queue, every lane is free, and all 64 take new camera rays. Either way
+// no phase runs for a fraction of the lanes (before: the shading of ~41 hits ran with the
+// other lanes masked off in every iteration, and a lane that freed up set up its camera ray
+// through an LDS staging slot).
+//
+// Finished radiances are staged in LDS as packed 12-byte items of a SUB-JOB (two buffers,
+// ping-pong) and leave as whole 64-byte lines. A path that outlives its sub-job's buffer does
+// not stall the wave: the buffer is written out when the wave needs it, and the straggler
+// stores its 12 bytes itself when it ends (it recognises that from its item number alone).
 #ifndef SRT_SUB_PLAIN
-#define SRT_SUB_PLAIN 128
+#define SRT_SUB_PLAIN 64
 #endif
 #ifndef SRT_SUB_MODELS
-#define SRT_SUB_MODELS 256
+#define SRT_SUB_MODELS 128
+#endif
+#ifndef SRT_SUB_BVH
+#define SRT_SUB_BVH 128
+#endif
+// SHADE runs when hits + queued paths reach this many lanes (64 = always a full wave)
+#ifndef SRT_SHADE_MIN
+#define SRT_SHADE_MIN 64
+#endif
+// paths the hit queue holds; when hits + queued paths exceed it they are shaded even if they do not fill the wave
+#ifndef SRT_HQ_CAP
+#define SRT_HQ_CAP 48
+#endif
+// new camera rays are only set up when at least this many lanes are free
+#ifndef SRT_REFILL_MIN
+#define SRT_REFILL_MIN 32
+#endif
+
+// Development aid (-DSRT_PHASE_CLOCK): per-wave cycles spent in each phase of the main loop, summed into the wave's
+// counter line (slots 8..15: extend, ring, shade, park, deliver, refill, spare, total); srt_debug_counters reports them.
+#ifdef SRT_PHASE_CLOCK
+#define SRT_CLK_DECL unsigned long long clk_t[8] = {0, 0, 0, 0, 0, 0, 0, 0}, clk_last = __builtin_amdgcn_s_memtime(), clk_start = clk_last
+#define SRT_CLK(i)                                                  \
+	do {                                                            \
+		const unsigned long long now_ = __builtin_amdgcn_s_memtime(); \
+		clk_t[i] += now_ - clk_last;                                \
+		clk_last = now_;                                            \
+	} while (0)
+#else
+#define SRT_CLK_DECL
+#define SRT_CLK(i)
 #endif
 
 namespace {
-// One wave writes a finished sub-job's radiances (n items, 16-byte slots {r, g, b, -} in
-// LDS) to HBM as packed 12-byte items: whole 64-byte lines, 16 B per lane per store. dst is
-// 16-byte aligned (sub-jobs start on multiples of the sub-job size, a multiple of 4 items).
+// One wave writes a sub-job's radiances (n items, packed 12-byte items in LDS) to HBM: whole
+// 64-byte lines, 16 B per lane per store. Both sides are 16-byte aligned (sub-jobs start on
+// multiples of 4 items).
 //
 // One-wave workgroup: the LDS executes this wave's ds_write / ds_read in program order, so no
-// s_barrier is needed (a __syncthreads() would also wait, vmcnt(0), for the previous flush's
-// global stores to drain). Only keep the compiler from reordering across these points.
+// s_barrier is needed; only keep the compiler from reordering across these points.
 __device__ __forceinline__ void flush_stage(const float *__restrict__ src, float *__restrict__ dst, uint32_t n_items, int lane) {
 	asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 	const uint32_t n = n_items * 3u, n4 = n >> 2;
+	const float4 *__restrict__ s4 = reinterpret_cast<const float4 *>(src);
 	float4 *__restrict__ d4 = reinterpret_cast<float4 *>(dst);
-	for (uint32_t i = (uint32_t)lane; i < n4; i += 64u) {
-		// packed floats 4i .. 4i+3 live in slots (4i+c)/3, component (4i+c)%3
-		const uint32_t f = 4u * i, it = f / 3u, c = f - 3u * it; // c in {0,1,2}
-		const float *__restrict__ a = src + 4u * it + c;
-		// the four floats never leave slots it and it+1 (+2 when c == 2): walk them explicitly
-		float v0 = a[0];
-		float v1 = (c + 1u < 3u) ? a[1] : a[2];              // c == 2: skip the pad, first float of the next slot
-		float v2 = (c == 0u) ? a[2] : a[3];
-		float v3 = a[4];
-		d4[i] = make_float4(v0, v1, v2, v3);
+	for (uint32_t i = (uint32_t)lane; i < n4; i += 64u) d4[i] = s4[i];
+	for (uint32_t f = (n4 << 2) + (uint32_t)lane; f < n; f += 64u) dst[f] = src[f];
+	asm volatile("" ::: "memory");
+}
+
+// wave-uniform bookkeeping of the two staged sub-jobs
+struct Stage {
+	uint32_t base0 = 0, base1 = 0;   // first item of the sub-job in buffer 0 / 1
+	uint32_t total0 = 0, total1 = 0; // its items (0 = buffer free)
+	uint32_t pend0 = 0, pend1 = 0;   // of those handed out, how many have not delivered their radiance yet
+};
+
+// A path has ended with radiance c: into its sub-job's staging slot if that sub-job is still staged,
+// else (its buffer was needed and written out meanwhile) straight to HBM. f0 / f1 report which.
+template <uint32_t SUB>
+__device__ __forceinline__ void deliver(const Stage &st, float *__restrict__ stage, float *__restrict__ radiance, uint32_t item, f3 c, bool &f0, bool &f1) {
+	const uint32_t d0 = item - st.base0, d1 = item - st.base1;
+	if (d0 < st.total0) {
+		float *s = stage + 3u * d0;
+		s[0] = c.x, s[1] = c.y, s[2] = c.z;
+		f0 = true;
+	} else if (d1 < st.total1) {
+		float *s = stage + 3u * (SUB + d1);
+		s[0] = c.x, s[1] = c.y, s[2] = c.z;
+		f1 = true;
+	} else {
+		float *g = radiance + 3ull * item;
+		g[0] = c.x, g[1] = c.y, g[2] = c.z;
 	}
-	for (uint32_t f = (n4 << 2) + (uint32_t)lane; f < n; f += 64u) {
-		const uint32_t it = f / 3u;
-		dst[f] = src[4u * it + (f - 3u * it)];
+}
+
+// Evaluate the sky for the first n queued escapes (n <= 64), one per lane, and finish their
+// paths: mask *= sky; color += mask (render.cl:464-465). Called with all 64 lanes in
+// wave-uniform control flow.
+template <uint32_t SUB>
+__device__ __forceinline__ void resolve_ring(const TraceParams &p, const float *__restrict__ ring, uint32_t n, Stage &st, float *__restrict__ stage, int lane) {
+	asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+	bool f0 = false, f1 = false;
+	if ((uint32_t)lane < n) {
+		const f3 d = mk(ring[0 * 64 + lane], ring[1 * 64 + lane], ring[2 * 64 + lane]);
+		f3 m = mk(ring[3 * 64 + lane], ring[4 * 64 + lane], ring[5 * 64 + lane]);
+		f3 c = mk(ring[6 * 64 + lane], ring[7 * 64 + lane], ring[8 * 64 + lane]);
+		const uint32_t item = dm_f2u(ring[9 * 64 + lane]);
+		m = m * sky_box(p, d);
+		c = c + m;
+		deliver<SUB>(st, stage, p.radiance, item, c, f0, f1);
 	}
+	st.pend0 -= (uint32_t)__popcll(__ballot(f0));
+	st.pend1 -= (uint32_t)__popcll(__ballot(f1));
 	asm volatile("" ::: "memory");
 }
 } // namespace
 
-// Waves per SIMD the register allocator is asked for (A/B on MI355X, profiles/): the
-// sphere/plane kernel is fastest at 5 (96 VGPRs), the mesh kernels at 4 (128 VGPRs: the
-// triangle loop spills at 96).
+// Waves per SIMD the register allocator is asked for. LDS per wave (two staging buffers, sky
+// ring, hit queue, scene records) is ~10 KB, which is what bounds residency.
 #ifndef SRT_TRACE_WAVES_PER_SIMD
 #define SRT_TRACE_WAVES_PER_SIMD 5
 #endif
 #ifndef SRT_TRACE_WAVES_PER_SIMD_MODELS
 #define SRT_TRACE_WAVES_PER_SIMD_MODELS 4
 #endif
-// The BVH walk is bound by the latency of its dependent per-lane loads, not by issue, so more
-// resident waves help even at the price of ~30 spilled registers, and 64-item sub-jobs keep the
-// LDS footprint of 24 waves per CU inside 160 KB. A/B on MI355X (profiles/README.md), configs[4]
-// at full size: 4 waves x 256 items 95.7 ms, 4 x 64 90.5, 5 x 64 81.3, 6 x 64 75.7 (configs[2],
-// two 968-triangle trees: 78.5 / 85.9 / 81.1 / 80.5).
 #ifndef SRT_TRACE_WAVES_PER_SIMD_BVH
-#define SRT_TRACE_WAVES_PER_SIMD_BVH 6
-#endif
-#ifndef SRT_SUB_BVH
-#define SRT_SUB_BVH 64
+#define SRT_TRACE_WAVES_PER_SIMD_BVH 4
 #endif
 
 // HAS_MODELS = false compiles every AABB / triangle / mesh-normal path out: scenes of
-// spheres and planes (BASELINE configs 0, 1, 3) get a leaner kernel (fewer registers, no
-// spills, smaller code); the host picks the instantiation from the scene.
+// spheres and planes (BASELINE configs 0, 1, 3) get a leaner kernel; the host picks the
+// instantiation from the scene.
 template <bool COUNT_TRIS, bool USE_LDS, bool HAS_MODELS, bool USE_BVH>
 __global__ __launch_bounds__(64, USE_BVH ? SRT_TRACE_WAVES_PER_SIMD_BVH : HAS_MODELS ? SRT_TRACE_WAVES_PER_SIMD_MODELS : SRT_TRACE_WAVES_PER_SIMD) void srt_trace_kernel(const TraceParams p) {
-	extern __shared__ float4 lds[]; // [2*n_shapes] winner records, [4*n_materials] materials, [2][SRT_SUB] staging slots
-	constexpr uint32_t SRT_SUB = USE_BVH ? SRT_SUB_BVH : HAS_MODELS ? SRT_SUB_MODELS : SRT_SUB_PLAIN;
+	extern __shared__ float4 lds[]; // [2*n_shapes] winner records, [4*n_materials] materials, staging, sky ring, hit queue
+	constexpr uint32_t SUB = USE_BVH ? SRT_SUB_BVH : HAS_MODELS ? SRT_SUB_MODELS : SRT_SUB_PLAIN;
 	const int width = p.rd.width;
 	const int lane = threadIdx.x;
 	const int ns = p.rd.num_samples;
@@ -625,225 +691,173 @@ __global__ __launch_bounds__(64, USE_BVH ? SRT_TRACE_WAVES_PER_SIMD_BVH : HAS_MO
 	}
 
 	// ---- work distribution: one work-item = one (pixel, sample) path -------------------
-	// Items of this dispatch: item = q * batch_samples + k, q = packed owned pixel
-	// (row-major), sample = first_sample + k. Consecutive items are consecutive samples of
-	// one pixel, so the 64 lanes of a wave start out on (nearly) the same camera ray.
-	// Persistent waves reserve jobs of `job_items` items from ONE global cursor; a lane whose
-	// path ends takes the wave's next item in the same iteration (ballot + mbcnt), so every
-	// lane stays busy until the global queue is dry. Radiance goes to radiance[item];
-	// srt_reduce_kernel adds it up per pixel in sample order.
-	const unsigned long long total_items = p.total_items;
+	// Items of this dispatch: item = q * batch_samples + k, q = packed owned pixel (row-major),
+	// sample = first_sample + k; fewer than 2^32 per launch (the host sizes sample batches so).
+	// Consecutive items are consecutive samples of one pixel, so the 64 lanes of a wave start out
+	// on (nearly) the same camera ray. Persistent waves reserve chunks of p.job_items items from
+	// ONE global cursor (the first chunk of a wave is its own: chunk number = workgroup number, so
+	// thousands of waves starting together do not queue up on one atomic) and work through them in
+	// sub-jobs of SUB items, whose radiances are staged in LDS. srt_reduce_kernel adds the
+	// radiances up per pixel in sample order.
+	const uint32_t total_items = (uint32_t)p.total_items;
 	const uint32_t nbs = p.batch_samples;
-	// Global cursor -> chunk of p.job_items items per atomic -> sub-jobs of SRT_SUB items.
-	// A sub-job's radiances are staged in LDS (two buffers, ping-pong) and written to HBM in
-	// one fully coalesced burst of whole 64-byte lines when its last path has finished,
-	// instead of 12 scattered bytes per lane (which made the L2 fetch every line first).
-	// The first chunk of a wave is its own (chunk number = workgroup number): thousands of waves starting
-	// together would otherwise queue up on one atomic (0.37 -> 0.30 ms for an interactive-size frame).
-	// The shared cursor hands out the chunks behind those.
 	const unsigned long long own_chunks_end = (unsigned long long)gridDim.x * p.job_items;
-	unsigned long long chunk_cur = (unsigned long long)blockIdx.x * p.job_items, chunk_end = chunk_cur + p.job_items; // wave-uniform
-	if (chunk_end > p.total_items) chunk_end = p.total_items;
-	if (chunk_cur >= p.total_items) chunk_cur = chunk_end = 0;
-	unsigned long long base0 = 0, base1 = 0;                         // first item of the sub-job in buffer 0 / 1
-	uint32_t total0 = 0, total1 = 0;                                 // items of the sub-job staged in each buffer (0 = free)
-	uint32_t issued = 0, cur = 0;                                    // issue cursor of the current buffer `cur`
+	uint32_t chunk_cur = 0, chunk_end = 0; // wave-uniform
+	if ((unsigned long long)blockIdx.x * p.job_items < (unsigned long long)total_items) {
+		chunk_cur = blockIdx.x * p.job_items;
+		chunk_end = (total_items - chunk_cur < p.job_items) ? total_items : chunk_cur + p.job_items;
+	}
 	bool queue_dry = (total_items == 0);
-	float4 *__restrict__ stage = lds + p.stage_off; // [2][SRT_SUB] 16-byte slots: {dir.xyz, seed} before the trace, {r, g, b, -} after
-	float *__restrict__ ring = reinterpret_cast<float *>(stage + 2u * SRT_SUB); // [10][64] escaped paths awaiting their sky lookup
-	uint32_t ring_count = 0;                                                    // wave-uniform
+	Stage st;
+	uint32_t qpix0 = 0, qpix1 = 0, koff0 = 0, koff1 = 0; // pixel and sample offset of each staged sub-job's first item
+	uint32_t issued = 0, cur = 0;                        // items of buffer `cur` handed out so far
+	float *__restrict__ stage = reinterpret_cast<float *>(lds + p.stage_off); // [2][SUB] packed {r, g, b}
+	float *__restrict__ ring = stage + 2u * SUB * 3u;                          // [10][64] escaped paths awaiting their sky lookup
+	float *__restrict__ hq = ring + 10u * 64u;                                 // [16..18][HQ] paths that hit, awaiting their bounce (FIFO)
+	constexpr uint32_t HQ = SRT_HQ_CAP;
+	uint32_t ring_count = 0, hq_head = 0, hq_count = 0;                        // wave-uniform
 
 	f3 org = mk(0.f, 0.f, 0.f), dir = mk(0.f, 0.f, 0.f), mask = mk(1.f, 1.f, 1.f), color = mk(0.f, 0.f, 0.f);
 	uint32_t seed = 0;
-	uint32_t slot = 0; // lane's item = base[bi] + slot
-	uint32_t bi = 0;
+	uint32_t item = 0;
 	int bounce = 0;
-	bool active = false;
+	int best = -1;
+	uint32_t best_tri = 0; // index inside the model; with a BVH: absolute triangle record
+	uint32_t best_j = 0;   // BVH only: index inside the model
+	bool active = false;   // the lane holds a ray that awaits closest_intersection
 	// rays / sky / paths are counted per WAVE with popcounts of the exec mask (scalar adds, no
 	// VGPRs); only the instrumented triangle counters stay per lane.
-	unsigned long long w_rays = 0, w_sky = 0, w_paths = 0;
+	unsigned long long w_rays = 0, w_sky = 0, w_paths = 0, w_orphans = 0, w_evict = 0, w_iter = 0, w_shade = 0;
 	uint32_t n_tri = 0, n_tri_u = 0;
 	uint32_t idle_spins = 0;
 
+	SRT_CLK_DECL;
 	for (;;) {
-		// ---- refill idle lanes -----------------------------------------------------------
-		const unsigned long long want = __ballot(!active);
-		if (want != 0ull && !queue_dry) {
-			const uint32_t cur_total0 = cur ? total1 : total0;
-			if (cur_total0 == 0u || issued == cur_total0) {
-				// current sub-job fully handed out (or already flushed / none yet): open the next one in
-				// the other buffer, if that is free
-				const uint32_t other = cur ^ 1u;
-				bool other_free = true;
-				if ((other ? total1 : total0) != 0u) {
-					if (ring_count != 0u) { // queued escapes may belong to the buffer we are about to judge
-						resolve_ring(p, ring, ring_count, stage, lane);
-						ring_count = 0;
-					}
-					// The other buffer still holds the previous sub-job. It is complete exactly when no
-					// lane is still tracing one of its items: then write it out as whole 64-byte lines.
-					if (__ballot(active && bi == other) != 0ull) {
-						other_free = false; // idle lanes wait an iteration; paths end within num_bounces iterations
-					} else if (other) {
-						flush_stage(reinterpret_cast<const float *>(stage + SRT_SUB), p.radiance + base1 * 3ull, total1, lane);
-						total1 = 0u;
-					} else {
-						flush_stage(reinterpret_cast<const float *>(stage), p.radiance + base0 * 3ull, total0, lane);
-						total0 = 0u;
-					}
-				}
-				if (other_free) {
-					if (chunk_cur == chunk_end) {
-						unsigned long long start = total_items;
-						if (own_chunks_end < total_items) { // else every chunk is some wave's first: nothing to ask the cursor for
-							if (lane == 0) start = atomicAdd(p.queue, (unsigned long long)p.job_items);
-							start = (unsigned long long)__shfl((long long)start, 0) + own_chunks_end;
-						}
-						if (start >= total_items) {
-							queue_dry = true;
-						} else {
-							chunk_cur = start;
-							chunk_end = start + p.job_items < total_items ? start + p.job_items : total_items;
-						}
-					}
-					if (!queue_dry) {
-						const unsigned long long left = chunk_end - chunk_cur;
-						const uint32_t n = left < (unsigned long long)SRT_SUB ? (uint32_t)left : (uint32_t)SRT_SUB;
-						if (other) base1 = chunk_cur, total1 = n;
-						else base0 = chunk_cur, total0 = n;
-						// Camera rays of the WHOLE sub-job now, all 64 lanes busy (render.cl:488,496-516), parked
-						// in the staging slots as {dir, seed after the two jitter draws}; a lane that later
-						// takes an item only reads its slot. (One ray set-up per item instead of the set-up
-						// code running, mostly masked off, in every iteration of the segment loop.)
-						const unsigned long long q0 = chunk_cur / nbs; // one 64-bit division per sub-job
-						const uint32_t k0 = (uint32_t)(chunk_cur - q0 * nbs);
-						float4 *__restrict__ slots = stage + other * (uint32_t)SRT_SUB;
-						for (uint32_t sl = (uint32_t)lane; sl < n; sl += 64u) {
-							const uint32_t off = k0 + sl; // < nbs + SRT_SUB: 32-bit math from here
-							const uint32_t dq = (nbs >= (uint32_t)SRT_SUB) ? (off >= nbs ? 1u : 0u) : off / nbs;
-							const uint32_t q = (uint32_t)q0 + dq; // owned pixels < 2^31 (checked by the host)
-							const uint32_t sample = p.first_sample + (off - dq * nbs);
-							const uint32_t lrow = q / (uint32_t)width;
-							const int px = (int)(q - lrow * (uint32_t)width);
-							const int py = global_row((int)lrow, p.rank, p.world, p.rows_per_block);
-							const uint32_t id = (uint32_t)px + (uint32_t)py * (uint32_t)width;
-							uint32_t sd_ = (sample + id * (uint32_t)ns) * p.rd.time * 5304u;
-							float ndc_x = ((float)px + random_float(sd_)) / p.f_width;
-							float ndc_y = ((float)py + random_float(sd_)) / p.f_height;
-							float sx = ((2.f * ndc_x - 1.f) * p.rd.aspect_ratio) * p.rd.fov_scale;
-							float sy = (1.f - 2.f * ndc_y) * p.rd.fov_scale;
-							f3 d0 = normalize3(mat_by_vec(p.rd.camera_to_world, mk(sx, sy, -1.0f), 0.0f));
-							slots[sl] = make_float4(d0.x, d0.y, d0.z, dm_u2f(sd_));
-						}
-						asm volatile("" ::: "memory");
-						chunk_cur += n;
-						cur = other;
-						issued = 0;
-					}
-				}
-			}
-			const uint32_t cur_total = cur ? total1 : total0;
-			if (issued < cur_total) {
-				const uint32_t avail = cur_total - issued;
-				const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(want >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)want, 0u));
-				const uint32_t nwant = (uint32_t)__popcll(want);
-				if (!active && rank < avail) {
-					// ---- next path: its camera ray was prepared when the sub-job was opened ----
-					slot = issued + rank;
-					bi = cur;
-					const float4 ray = stage[cur * (uint32_t)SRT_SUB + slot];
-					dir = mk(ray.x, ray.y, ray.z);
-					seed = dm_f2u(ray.w);
-					org = mk(p.rd.camera_to_world[3].x, p.rd.camera_to_world[3].y, p.rd.camera_to_world[3].z);
-					mask = mk(1.f, 1.f, 1.f);
-					color = mk(0.f, 0.f, 0.f);
-					bounce = 0;
-					active = true;
-				}
-				const uint32_t handed = nwant < avail ? nwant : avail;
-				issued += handed;
-				w_paths += handed;
-			}
-		}
-		if (!__any(active)) {
-			if (queue_dry) break;
-			// the sub-job ran out mid-refill: open the next one. Bounded: a wave that spins here
-			// without ever getting work leaves with the watchdog counter set instead of hanging.
-			if (++idle_spins > (1u << 20)) {
-				if (lane == 0) atomicAdd(&p.counters[SRT_CTR_WATCHDOG], 1ull);
-				break;
-			}
-			continue;
-		}
-		idle_spins = 0;
+		bool hit = false, missed = false, fin = false;
+		w_iter++;
+		SRT_CLK(6);
+		// ================= EXTEND: closest_intersection (render.cl:293-378), winner deferred =================
+		if (__any(active)) {
+			if (nb > 0) w_rays += (unsigned long long)__popcll(__ballot(active));
+			if (active) {
+				if (nb <= 0) { // render.cl:403: no bounce loop at all -> colour 0
+					fin = true;
+				} else {
+					float tmin = DM_INF_F;
+					best = -1;
+					best_tri = 0, best_j = 0;
+					f3 inv = mk(0.f, 0.f, 0.f);
+					if (HAS_MODELS) inv = mk(1.0f / dir.x, 1.0f / dir.y, 1.0f / dir.z);
 
-		if (nb > 0) w_rays += (unsigned long long)__popcll(__ballot(active));
-		bool missed = false;
-		if (active) {
-			bool done = (nb <= 0); // render.cl:403: no bounce loop at all -> colour 0
-			if (!done) {
-			// ---- closest_intersection (render.cl:293-378), winner deferred ----
-			float tmin = DM_INF_F;
-			int best = -1;
-			uint32_t best_tri = 0; // index inside the model; with a BVH: absolute triangle record
-			uint32_t best_j = 0;   // BVH only: index inside the model
-			f3 inv = mk(0.f, 0.f, 0.f);
-			if (HAS_MODELS) inv = mk(1.0f / dir.x, 1.0f / dir.y, 1.0f / dir.z);
-
-			for (int r = 0; r < p.num_runs; r++) {
-				float rr[4];
-				ld_uniform<4, 16>(reinterpret_cast<const float *>(runs + r), rr);
-				ShapeRun run;
-				run.type = (int32_t)f2u(rr[0]), run.first_shape = f2u(rr[1]), run.count = f2u(rr[2]), run.data_off = f2u(rr[3]);
-				const float *__restrict__ d = run_data + run.data_off;
-				const int base = (int)run.first_shape;
-				const uint32_t cnt = run.count;
-				if (run.type == SRT_SHAPE_SPHERE) {
-					for (uint32_t k = 0; k < cnt; k += 4) {
-						const Blk16 b = ld_blk16(d + 4 * k);
-						test_sphere(b.v[0], b.v[1], b.v[2], b.v[3], org, dir, base + (int)k, tmin, best);
-						if (k + 1 < cnt) test_sphere(b.v[4], b.v[5], b.v[6], b.v[7], org, dir, base + (int)k + 1, tmin, best);
-						if (k + 2 < cnt) test_sphere(b.v[8], b.v[9], b.v[10], b.v[11], org, dir, base + (int)k + 2, tmin, best);
-						if (k + 3 < cnt) test_sphere(b.v[12], b.v[13], b.v[14], b.v[15], org, dir, base + (int)k + 3, tmin, best);
-					}
-				} else if (run.type == SRT_SHAPE_PLANE) {
-					for (uint32_t k = 0; k < cnt; k += 2) {
-						const Blk16 b = ld_blk16(d + 8 * k);
-						test_plane(b.v[0], b.v[1], b.v[2], b.v[4], b.v[5], b.v[6], org, dir, base + (int)k, tmin, best);
-						if (k + 1 < cnt) test_plane(b.v[8], b.v[9], b.v[10], b.v[12], b.v[13], b.v[14], org, dir, base + (int)k + 1, tmin, best);
-					}
-				} else if (HAS_MODELS && run.type == SRT_SHAPE_MODEL) {
-					for (uint32_t k = 0; k < cnt; k += 2) {
-						const Blk16 b = ld_blk16(d + 8 * k);
-						// the model's own box first, exactly as the reference (render.cl:316-323), then its triangles
-						if (test_aabb(b.v[0], b.v[1], b.v[2], b.v[4], b.v[5], b.v[6], org, inv, tmin)) {
-							if (USE_BVH) {
-								if (f2u(b.v[7]) != 0u)
-									walk_bvh<COUNT_TRIS>(p.bvh_nodes, p.bvh_tris, f2u(b.v[3]), org, dir, base + (int)k, tmin, best, best_tri, best_j, n_tri, n_tri_u);
-							} else {
-								if (COUNT_TRIS) n_tri += f2u(b.v[7]);
-								test_triangles<COUNT_TRIS>(wtris, f2u(b.v[3]), f2u(b.v[7]), org, dir, base + (int)k, tmin, best, best_tri, n_tri_u);
+					// Blocks of same-type shapes in array order; header and data of the NEXT block are fetched (scalar
+					// loads, one allocated past the end) before this one is tested, so only the first block's load
+					// latency is exposed per segment.
+					const int n_blocks = p.num_runs;
+					float hd[4];
+					ld_uniform<4, 16>(reinterpret_cast<const float *>(runs), hd);
+					Blk16 b = ld_blk16(run_data);
+					for (int r = 0; r < n_blocks; r++) {
+						float hn[4];
+						ld_uniform<4, 16>(reinterpret_cast<const float *>(runs + r + 1), hn);
+						const Blk16 bn = ld_blk16(run_data + 16 * (r + 1));
+						const int type = (int32_t)f2u(hd[0]);
+						const int base = (int)f2u(hd[1]);
+						if (type == SRT_SHAPE_SPHERE) {
+							test_spheres4(b, org, dir, base, tmin, best);
+						} else if (type == SRT_SHAPE_PLANE) {
+							test_planes2(b, org, dir, base, tmin, best);
+						} else if (HAS_MODELS && type == SRT_SHAPE_MODEL) {
+							// the model's own box first, exactly as the reference (render.cl:316-323), then its triangles
+							if (test_aabb(b.v[0], b.v[1], b.v[2], b.v[4], b.v[5], b.v[6], org, inv, tmin)) {
+								if (USE_BVH) {
+									if (f2u(b.v[7]) != 0u)
+										walk_bvh<COUNT_TRIS>(p.bvh_nodes, p.bvh_tris, f2u(b.v[3]), org, dir, base, tmin, best, best_tri, best_j, n_tri, n_tri_u);
+								} else {
+									if (COUNT_TRIS) n_tri += f2u(b.v[7]);
+									test_triangles<COUNT_TRIS>(wtris, f2u(b.v[3]), f2u(b.v[7]), org, dir, base, tmin, best, best_tri, n_tri_u);
+								}
+							}
+							if (f2u(hd[2]) > 1u && test_aabb(b.v[8], b.v[9], b.v[10], b.v[12], b.v[13], b.v[14], org, inv, tmin)) {
+								if (USE_BVH) {
+									if (f2u(b.v[15]) != 0u)
+										walk_bvh<COUNT_TRIS>(p.bvh_nodes, p.bvh_tris, f2u(b.v[11]), org, dir, base + 1, tmin, best, best_tri, best_j, n_tri, n_tri_u);
+								} else {
+									if (COUNT_TRIS) n_tri += f2u(b.v[15]);
+									test_triangles<COUNT_TRIS>(wtris, f2u(b.v[11]), f2u(b.v[15]), org, dir, base + 1, tmin, best, best_tri, n_tri_u);
+								}
 							}
 						}
-						if (k + 1 < cnt && test_aabb(b.v[8], b.v[9], b.v[10], b.v[12], b.v[13], b.v[14], org, inv, tmin)) {
-							if (USE_BVH) {
-								if (f2u(b.v[15]) != 0u)
-									walk_bvh<COUNT_TRIS>(p.bvh_nodes, p.bvh_tris, f2u(b.v[11]), org, dir, base + (int)k + 1, tmin, best, best_tri, best_j, n_tri, n_tri_u);
-							} else {
-								if (COUNT_TRIS) n_tri += f2u(b.v[15]);
-								test_triangles<COUNT_TRIS>(wtris, f2u(b.v[11]), f2u(b.v[15]), org, dir, base + (int)k + 1, tmin, best, best_tri, n_tri_u);
-							}
-						}
+						hd[0] = hn[0], hd[1] = hn[1], hd[2] = hn[2], hd[3] = hn[3];
+						b = bn;
 					}
+					// a shape without a material counts as a miss (render.cl:404: material_index >= 0)
+					int material_index = -1;
+					if (best >= 0) material_index = USE_LDS ? (int)f2u(reinterpret_cast<const float *>(lds)[8 * best + 1]) : p.winners[best].material;
+					hit = material_index >= 0;
+					missed = !hit;
+					if (hit) org = org + dir * tmin; // rayhit->position (render.cl:312,343,362)
 				}
+				active = false;
 			}
+		}
 
-			// ---- winner: position, normal, material (render.cl:311-312,337-343,361-362,372-375) ----
-			int material_index = -1;
-			f3 pos = org, nrm = mk(0.f, 0.f, 0.f);
-			bool front = false;
-			if (best >= 0) {
-				int type;
+		SRT_CLK(0);
+		// ---- escaped paths queue for the sky (wave-uniform control flow) ----
+		const unsigned long long mm = __ballot(missed);
+		if (mm != 0ull) {
+			const uint32_t n_miss = (uint32_t)__popcll(mm);
+			if (ring_count + n_miss > 64u) {
+				resolve_ring<SUB>(p, ring, ring_count, st, stage, lane);
+				ring_count = 0;
+			}
+			if (missed) {
+				const uint32_t e = ring_count + __builtin_amdgcn_mbcnt_hi((uint32_t)(mm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mm, 0u));
+				ring[0 * 64 + e] = dir.x, ring[1 * 64 + e] = dir.y, ring[2 * 64 + e] = dir.z;
+				ring[3 * 64 + e] = mask.x, ring[4 * 64 + e] = mask.y, ring[5 * 64 + e] = mask.z;
+				ring[6 * 64 + e] = color.x, ring[7 * 64 + e] = color.y, ring[8 * 64 + e] = color.z;
+				ring[9 * 64 + e] = dm_u2f(item);
+			}
+			ring_count += n_miss;
+			w_sky += n_miss;
+		}
+
+		SRT_CLK(1);
+		// ================= SHADE or PARK =================
+		const unsigned long long hb = __ballot(hit);
+		const uint32_t n_hit = (uint32_t)__popcll(hb);
+		const uint32_t n_ready = n_hit + hq_count;
+		if (n_ready >= (uint32_t)SRT_SHADE_MIN || n_ready > HQ || (queue_dry && n_ready > 0u)) {
+			// lanes without a hit take the oldest waiting paths
+			const uint32_t n_free = 64u - n_hit;
+			const uint32_t n_pop = n_free < hq_count ? n_free : hq_count;
+			if (n_pop != 0u) {
+				asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+				const unsigned long long fb = ~hb;
+				const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(fb >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)fb, 0u));
+				if (!hit && rank < n_pop) {
+					uint32_t e = hq_head + rank;
+					e = e >= HQ ? e - HQ : e;
+					org = mk(hq[0 * HQ + e], hq[1 * HQ + e], hq[2 * HQ + e]);
+					dir = mk(hq[3 * HQ + e], hq[4 * HQ + e], hq[5 * HQ + e]);
+					mask = mk(hq[6 * HQ + e], hq[7 * HQ + e], hq[8 * HQ + e]);
+					color = mk(hq[9 * HQ + e], hq[10 * HQ + e], hq[11 * HQ + e]);
+					seed = dm_f2u(hq[12 * HQ + e]);
+					best = (int)dm_f2u(hq[13 * HQ + e]);
+					bounce = (int)dm_f2u(hq[14 * HQ + e]);
+					item = dm_f2u(hq[15 * HQ + e]);
+					if (HAS_MODELS) best_tri = dm_f2u(hq[16 * HQ + e]);
+					if (USE_BVH) best_j = dm_f2u(hq[17 * HQ + e]);
+					hit = true;
+				}
+				asm volatile("" ::: "memory");
+				hq_head += n_pop;
+				hq_head = hq_head >= HQ ? hq_head - HQ : hq_head;
+				hq_count -= n_pop;
+			}
+			w_shade++;
+			if (hit) {
+				// ---- winner: normal, material (render.cl:311-312,337-343,361-362,372-375); org = hit position ----
+				int type, material_index;
 				f3 wv;
 				float ww;
 				uint32_t first_wtri;
@@ -862,7 +876,8 @@ __global__ __launch_bounds__(64, USE_BVH ? SRT_TRACE_WAVES_PER_SIMD_BVH : HAS_MO
 					ww = wr->w;
 					first_wtri = wr->first_wtri;
 				}
-				pos = org + dir * tmin;
+				const f3 pos = org;
+				f3 nrm = mk(0.f, 0.f, 0.f);
 				if (type == SRT_SHAPE_SPHERE) {
 					nrm = div3(pos - wv, ww);
 				} else if (type == SRT_SHAPE_PLANE) {
@@ -871,7 +886,7 @@ __global__ __launch_bounds__(64, USE_BVH ? SRT_TRACE_WAVES_PER_SIMD_BVH : HAS_MO
 					const srt_model *__restrict__ m = &p.shapes[best].shape.model;
 					const float *__restrict__ w = USE_BVH ? p.bvh_tris + (size_t)best_tri * SRT_BVH_TRI_FLOATS
 					                                      : wtris + (size_t)(first_wtri + best_tri) * SRT_WTRI_FLOATS;
-					if (USE_BVH) best_tri = best_j;
+					const uint32_t tri_in_model = USE_BVH ? best_j : best_tri;
 					f3 v0 = mk(w[0], w[1], w[2]);
 					f3 e1 = mk(w[3], w[4], w[5]);
 					f3 e2 = mk(w[6], w[7], w[8]);
@@ -883,19 +898,17 @@ __global__ __launch_bounds__(64, USE_BVH ? SRT_TRACE_WAVES_PER_SIMD_BVH : HAS_MO
 					float w0 = (d11 * d20 - d01 * d21) / den;
 					float w1 = (d00 * d21 - d01 * d20) / den;
 					float w2 = 1.0f - w0 - w1;
-					const srt_triangle *__restrict__ tr = p.triangles + (m->triangle_index + best_tri);
+					const srt_triangle *__restrict__ tr = p.triangles + (m->triangle_index + tri_in_model);
 					f3 n = (ld3(tr->vertices[0].normal) * w2 + ld3(tr->vertices[1].normal) * w0) + ld3(tr->vertices[2].normal) * w1;
 					n = mat_by_vec(m->transform, n, 0.0f); // forward matrix, as the reference
 					nrm = normalize3(n);
 				}
-				front = dot3(nrm, dir) < 0.0f;
+				const bool front = dot3(nrm, dir) < 0.0f;
 				nrm = nrm * (front ? 1.0f : -1.0f);
-			}
 
-			if (material_index >= 0) {
 				if (p.rd.show_normals) {
 					color = mk(nrm.x * 0.5f + 0.5f, nrm.y * 0.5f + 0.5f, nrm.z * 0.5f + 0.5f); // render.cl:407-410
-					done = true;
+					fin = true;
 				} else {
 					float4 m0, m1, mc, me;
 					if (USE_LDS) {
@@ -909,9 +922,9 @@ __global__ __launch_bounds__(64, USE_BVH ? SRT_TRACE_WAVES_PER_SIMD_BVH : HAS_MO
 					const float transmittance = m1.x, ior = m1.y;
 					const f3 mcolor = mk(mc.x, mc.y, mc.z);
 					color = color + (mask * mk(me.x, me.y, me.z)) * emission_strength; // render.cl:413
-					done = (bounce == nb - 1);                                          // render.cl:415-416
-					if (!done) {
-						org = pos;
+					if (bounce == nb - 1) {                                             // render.cl:415-416
+						fin = true;
+					} else {
 						// cosine weighted direction: 6 draws (render.cl:421, 156-163)
 						float gx = random_normal(seed);
 						float gy = random_normal(seed);
@@ -949,47 +962,149 @@ __global__ __launch_bounds__(64, USE_BVH ? SRT_TRACE_WAVES_PER_SIMD_BVH : HAS_MO
 							}
 						}
 						dir = normalize3(dir);
-						org = org + (nrm * dm_sign(dot3(nrm, dir))) * 0.001f; // render.cl:462
+						org = pos + (nrm * dm_sign(dot3(nrm, dir))) * 0.001f; // render.cl:462
 						bounce++;
+						active = true;
 					}
 				}
-			} else {
-				// miss (render.cl:463-467): the sky is NOT evaluated here, where only ~1 lane in 5 would
-				// be busy; the lane queues {dir, mask, color, slot} in the wave's LDS ring below
-				missed = true;
 			}
+			SRT_CLK(2);
+		} else if (n_hit != 0u) {
+			// PARK: every hit waits in the queue; all lanes are free for new camera rays
+			if (hit) {
+				uint32_t e = hq_head + hq_count + __builtin_amdgcn_mbcnt_hi((uint32_t)(hb >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)hb, 0u));
+				e = e >= HQ ? e - HQ : e;
+				hq[0 * HQ + e] = org.x, hq[1 * HQ + e] = org.y, hq[2 * HQ + e] = org.z;
+				hq[3 * HQ + e] = dir.x, hq[4 * HQ + e] = dir.y, hq[5 * HQ + e] = dir.z;
+				hq[6 * HQ + e] = mask.x, hq[7 * HQ + e] = mask.y, hq[8 * HQ + e] = mask.z;
+				hq[9 * HQ + e] = color.x, hq[10 * HQ + e] = color.y, hq[11 * HQ + e] = color.z;
+				hq[12 * HQ + e] = dm_u2f(seed);
+				hq[13 * HQ + e] = dm_u2f((uint32_t)best);
+				hq[14 * HQ + e] = dm_u2f((uint32_t)bounce);
+				hq[15 * HQ + e] = dm_u2f(item);
+				if (HAS_MODELS) hq[16 * HQ + e] = dm_u2f(best_tri);
+				if (USE_BVH) hq[17 * HQ + e] = dm_u2f(best_j);
+			}
+			asm volatile("" ::: "memory");
+			hq_count += n_hit;
+			SRT_CLK(3);
+		}
 
-			} // !done
-			if (done) {
-				stage[bi * (uint32_t)SRT_SUB + slot] = make_float4(color.x, color.y, color.z, 0.f);
-				active = false;
+		// ---- paths that ended in this iteration hand in their radiance ----
+		if (__any(fin)) {
+			bool f0 = false, f1 = false;
+			if (fin) deliver<SUB>(st, stage, p.radiance, item, color, f0, f1);
+			const uint32_t n0 = (uint32_t)__popcll(__ballot(f0)), n1 = (uint32_t)__popcll(__ballot(f1));
+			st.pend0 -= n0, st.pend1 -= n1;
+			w_orphans += (unsigned long long)__popcll(__ballot(fin)) - n0 - n1;
+		}
+
+		SRT_CLK(4);
+		// ================= REFILL: free lanes take new camera rays =================
+		const unsigned long long freeb = __ballot(!active);
+		const uint32_t n_free = (uint32_t)__popcll(freeb);
+		if (!queue_dry && n_free >= (uint32_t)SRT_REFILL_MIN) {
+			const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(freeb >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)freeb, 0u));
+			uint32_t given = 0; // free lanes served so far (wave-uniform)
+			bool got = false;
+			uint32_t off = 0, qpix = 0;
+			while (given < n_free) {
+				const uint32_t cur_total = cur ? st.total1 : st.total0;
+				if (issued == cur_total) {
+					// the current sub-job is handed out (or there is none yet): open the next one in the other buffer
+					const uint32_t o = cur ^ 1u;
+					const uint32_t o_total = o ? st.total1 : st.total0;
+					if (o_total != 0u) {
+						// It still holds the sub-job before the current one: write it out. Paths of it that are still on
+						// their way (pend != 0) deliver to HBM themselves when they end; their stores must come after
+						// this one's, hence the wait.
+						const uint32_t o_pend = o ? st.pend1 : st.pend0;
+						flush_stage(stage + o * SUB * 3u, p.radiance + 3ull * (o ? st.base1 : st.base0), o_total, lane);
+						if (o_pend != 0u) {
+							asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+							w_evict++;
+						}
+						if (o) st.total1 = 0u, st.pend1 = 0u;
+						else st.total0 = 0u, st.pend0 = 0u;
+					}
+					if (chunk_cur == chunk_end) {
+						unsigned long long start = total_items;
+						if (own_chunks_end < (unsigned long long)total_items) { // else every chunk is some wave's first: nothing to ask the cursor for
+							if (lane == 0) start = atomicAdd(p.queue, (unsigned long long)p.job_items);
+							start = (unsigned long long)__shfl((long long)start, 0) + own_chunks_end;
+						}
+						if (start >= (unsigned long long)total_items) {
+							queue_dry = true;
+							break;
+						}
+						chunk_cur = (uint32_t)start;
+						chunk_end = (total_items - chunk_cur < p.job_items) ? total_items : chunk_cur + p.job_items;
+					}
+					const uint32_t left = chunk_end - chunk_cur;
+					const uint32_t n = left < SUB ? left : SUB;
+					const uint32_t q0 = chunk_cur / nbs; // one division per sub-job
+					const uint32_t k0 = chunk_cur - q0 * nbs;
+					if (o) st.base1 = chunk_cur, st.total1 = n, st.pend1 = 0u, qpix1 = q0, koff1 = k0;
+					else st.base0 = chunk_cur, st.total0 = n, st.pend0 = 0u, qpix0 = q0, koff0 = k0;
+					chunk_cur += n;
+					cur = o;
+					issued = 0;
+					continue;
+				}
+				const uint32_t avail = cur_total - issued;
+				const uint32_t take = avail < n_free - given ? avail : n_free - given;
+				if (!active && !got && rank >= given && rank < given + take) {
+					const uint32_t r = issued + (rank - given);
+					item = (cur ? st.base1 : st.base0) + r;
+					off = (cur ? koff1 : koff0) + r; // < nbs + SUB
+					qpix = cur ? qpix1 : qpix0;
+					got = true;
+				}
+				issued += take;
+				given += take;
+				if (cur) st.pend1 += take;
+				else st.pend0 += take;
+				w_paths += take;
+			}
+			if (got) {
+				// ---- camera ray (render.cl:488,496-516) ----
+				const uint32_t dq = (nbs >= SUB) ? (off >= nbs ? 1u : 0u) : off / nbs;
+				const uint32_t q = qpix + dq; // owned pixels < 2^31 (checked by the host)
+				const uint32_t sample = p.first_sample + (off - dq * nbs);
+				const uint32_t lrow = q / (uint32_t)width;
+				const int px = (int)(q - lrow * (uint32_t)width);
+				const int py = global_row((int)lrow, p.rank, p.world, p.rows_per_block);
+				const uint32_t id = (uint32_t)px + (uint32_t)py * (uint32_t)width;
+				seed = (sample + id * (uint32_t)ns) * p.rd.time * 5304u;
+				float ndc_x = ((float)px + random_float(seed)) / p.f_width;
+				float ndc_y = ((float)py + random_float(seed)) / p.f_height;
+				float sx = ((2.f * ndc_x - 1.f) * p.rd.aspect_ratio) * p.rd.fov_scale;
+				float sy = (1.f - 2.f * ndc_y) * p.rd.fov_scale;
+				dir = normalize3(mat_by_vec(p.rd.camera_to_world, mk(sx, sy, -1.0f), 0.0f));
+				org = mk(p.rd.camera_to_world[3].x, p.rd.camera_to_world[3].y, p.rd.camera_to_world[3].z);
+				mask = mk(1.f, 1.f, 1.f);
+				color = mk(0.f, 0.f, 0.f);
+				bounce = 0;
+				active = true;
 			}
 		}
 
-		// ---- deferred sky: queue this iteration's escaped paths (wave-uniform control flow) ----
-		const unsigned long long mm = __ballot(missed);
-		if (mm != 0ull) {
-			const uint32_t n_miss = (uint32_t)__popcll(mm);
-			if (ring_count + n_miss > 64u) {
-				resolve_ring(p, ring, ring_count, stage, lane);
-				ring_count = 0;
+		SRT_CLK(5);
+		if (!__any(active) && hq_count == 0u) {
+			if (queue_dry) break;
+			// Bounded: a wave that spins here without ever getting work leaves with the watchdog counter set instead of hanging.
+			if (++idle_spins > (1u << 20)) {
+				if (lane == 0) atomicAdd(&p.counters[SRT_CTR_WATCHDOG], 1ull);
+				break;
 			}
-			if (missed) {
-				const uint32_t e = ring_count + __builtin_amdgcn_mbcnt_hi((uint32_t)(mm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mm, 0u));
-				ring[0 * 64 + e] = dir.x, ring[1 * 64 + e] = dir.y, ring[2 * 64 + e] = dir.z;
-				ring[3 * 64 + e] = mask.x, ring[4 * 64 + e] = mask.y, ring[5 * 64 + e] = mask.z;
-				ring[6 * 64 + e] = color.x, ring[7 * 64 + e] = color.y, ring[8 * 64 + e] = color.z;
-				ring[9 * 64 + e] = dm_u2f(bi * SRT_SUB + slot);
-				active = false; // free for the next item; the radiance reaches the slot when the ring is resolved
-			}
-			ring_count += n_miss;
-			w_sky += n_miss;
+		} else {
+			idle_spins = 0;
 		}
 	}
-	// queue dry and no lane active: whatever is still staged is complete
-	if (ring_count != 0u) resolve_ring(p, ring, ring_count, stage, lane);
-	if (total0 != 0u) flush_stage(reinterpret_cast<const float *>(stage), p.radiance + base0 * 3ull, total0, lane);
-	if (total1 != 0u) flush_stage(reinterpret_cast<const float *>(stage + SRT_SUB), p.radiance + base1 * 3ull, total1, lane);
+	// queue dry, no lane active, nothing parked: whatever is still staged is complete
+	if (ring_count != 0u) resolve_ring<SUB>(p, ring, ring_count, st, stage, lane);
+	if (st.total0 != 0u) flush_stage(stage, p.radiance + 3ull * st.base0, st.total0, lane);
+	if (st.total1 != 0u) flush_stage(stage + SUB * 3u, p.radiance + 3ull * st.base1, st.total1, lane);
 
 	// per-wave counters: this wave's own 64-byte line, no atomics (device_types.h)
 	unsigned long long t3 = n_tri, t4 = n_tri_u;
@@ -1008,6 +1123,13 @@ __global__ __launch_bounds__(64, USE_BVH ? SRT_TRACE_WAVES_PER_SIMD_BVH : HAS_MO
 			w[3] += t3;
 			w[4] += t4;
 		}
+		w[5] += w_orphans + (w_evict << 40); // diagnostics (srt_debug_counters)
+		w[6] += w_iter;
+		w[7] += w_shade;
+#ifdef SRT_PHASE_CLOCK
+		for (int i = 0; i < 7; i++) w[8 + i] += clk_t[i];
+		w[15] += __builtin_amdgcn_s_memtime() - clk_start;
+#endif
 	}
 }
 
@@ -1138,7 +1260,7 @@ __global__ __launch_bounds__(256) void srt_resolve_kernel(const ResolveParams p)
 //   out[2] cos_2pi(t) != dm_cosf(t), t = 2pi*u    out[3] sum of bits of dm_logf(u)
 //   out[4] sum of bits of dm_cosf(t)              out[5] sum of bits of sqrt(u)
 //   out[6] sum of bits of dm_atan2pif(u - 0.5, 0.37 - u)   out[7] sum of bits of dm_powf(u, 25)
-//   out[8] div3(a, b) != a / b          out[9] normalize3(a) != a / sqrt(dot(a, a))
+//   out[8] div3(a, b) != a / b          out[9] sum of bits of normalize(u - 0.5, 0.37 - u, (r & 0xffff) * 1e-3 - 30)
 //          (a, b: random mantissas and signs, exponents straddling the fast paths' guards,
 //           zero components mixed in)
 //   out[10] sqrt_core(-2 log_unit(u)) != IEEE sqrt, the one call site without a guard
@@ -1192,8 +1314,9 @@ __global__ __launch_bounds__(256) void srt_selftest_kernel(unsigned long long *o
 		if ((r & 0xfffu) == 7u) a.z = dm_u2f(mix32(h)); // any bit pattern: denormals, inf, NaN
 		const float b = rand_float_exp(h, 127 - 44, 88);
 		bad_div += same_f3(div3(a, b), a / b) ? 0 : 1;
-		const f3 c = mk(rand_float_exp(h, 127 - 64, 108), a.y, a.z); // keeps dot(c, c) finite most of the time
-		bad_norm += same_f3(normalize3(c), c / __builtin_sqrtf(dot3(c, c))) ? 0 : 1;
+		// the built-in normalize on a vector made from r with plain float operations: checksum against the host build
+		const f3 nv = normalize3(mk(u - 0.5f, 0.37f - u, (float)(r & 0xffffu) * 1e-3f - 30.0f));
+		bad_norm += canon_bits(nv.x) + canon_bits(nv.y) + canon_bits(nv.z);
 	}
 	atomicAdd(&out[0], bad_sqrt);
 	atomicAdd(&out[1], bad_log);
@@ -1221,37 +1344,53 @@ int srt_trace_waves_per_simd(int has_models, int use_bvh) {
 }
 int srt_sub_job_items(int has_models, int use_bvh) { return !has_models ? SRT_SUB_PLAIN : use_bvh ? SRT_SUB_BVH : SRT_SUB_MODELS; }
 
+int srt_trace_lds_floats(int has_models, int use_bvh) {
+	// two staging buffers of packed 12-byte items, the sky ring (10 fields), the hit queue (16..18 fields)
+	const int sub = srt_sub_job_items(has_models, use_bvh);
+	return 2 * sub * 3 + 10 * 64 + (has_models ? (use_bvh ? 18 : 17) : 16) * SRT_HQ_CAP;
+}
+
+namespace {
+typedef void (*TraceKernel)(const TraceParams);
+TraceKernel pick_trace_kernel(bool models, bool use_bvh, bool use_lds, bool count_triangles) {
+	if (!models) return use_lds ? srt_trace_kernel<false, true, false, false> : srt_trace_kernel<false, false, false, false>;
+	if (use_bvh) {
+		if (use_lds) return count_triangles ? srt_trace_kernel<true, true, true, true> : srt_trace_kernel<false, true, true, true>;
+		return count_triangles ? srt_trace_kernel<true, false, true, true> : srt_trace_kernel<false, false, true, true>;
+	}
+	if (use_lds) return count_triangles ? srt_trace_kernel<true, true, true, false> : srt_trace_kernel<false, true, true, false>;
+	return count_triangles ? srt_trace_kernel<true, false, true, false> : srt_trace_kernel<false, false, true, false>;
+}
+// winners + materials go to LDS when small enough not to cost occupancy
+size_t scene_lds_bytes(const TraceParams &p) {
+	const size_t scene = (size_t)p.sd.num_shapes * sizeof(WinnerRec) + (size_t)p.num_materials * sizeof(srt_material);
+	return scene <= 4608 ? scene : 0; // both record types are multiples of 16 B
+}
+} // namespace
+
+// Persistent waves (= one-wave workgroups) of this launch configuration that one CU holds at once, as the runtime
+// computes it from the kernel's registers and its dynamic LDS; the grid must not exceed CUs x this, or the surplus
+// waves would only start -- each with a first chunk of its own -- when others have drained the queue.
+int srt_trace_resident_waves_per_cu(const TraceParams &p, bool count_triangles) {
+	const size_t scene_lds = scene_lds_bytes(p);
+	const size_t need = scene_lds + (size_t)srt_trace_lds_floats(p.num_models > 0, p.use_bvh) * sizeof(float);
+	int blocks = 0;
+	if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, pick_trace_kernel(p.num_models > 0, p.use_bvh != 0, scene_lds != 0, count_triangles), 64, need) != hipSuccess ||
+	    blocks <= 0) {
+		(void)hipGetLastError();
+		blocks = 4 * srt_trace_waves_per_simd(p.num_models > 0, p.use_bvh);
+	}
+	return blocks;
+}
+
 void srt_launch_trace(TraceParams p, bool count_triangles, int num_waves, void *stream) {
 	if (p.total_items == 0 || num_waves <= 0) return;
 	dim3 grid((unsigned)num_waves), block(64);
-	// winners + materials go to LDS when small enough not to cost occupancy (20 waves/CU x (3 + 4.5) KB < 160 KB)
-	const size_t scene = (size_t)p.sd.num_shapes * sizeof(WinnerRec) + (size_t)p.num_materials * sizeof(srt_material);
-	const bool use_lds = scene <= 4608;
-	const size_t scene_lds = use_lds ? scene : 0; // both record types are multiples of 16 B
+	const size_t scene_lds = scene_lds_bytes(p);
 	p.lds_bytes = (uint32_t)scene_lds;
 	p.stage_off = (uint32_t)(scene_lds / sizeof(float4));
-	const size_t need = scene_lds + 2u * (size_t)srt_sub_job_items(p.num_models > 0, p.use_bvh) * sizeof(float4) + 10u * 64u * sizeof(float);
-	hipStream_t st = (hipStream_t)stream;
-	const bool models = p.num_models > 0;
-	auto go = [&](auto kernel) { hipLaunchKernelGGL(kernel, grid, block, need, st, p); };
-	if (!models) {
-		if (use_lds) go(srt_trace_kernel<false, true, false, false>);
-		else go(srt_trace_kernel<false, false, false, false>);
-	} else if (p.use_bvh) {
-		if (use_lds) {
-			if (count_triangles) go(srt_trace_kernel<true, true, true, true>);
-			else go(srt_trace_kernel<false, true, true, true>);
-		} else {
-			if (count_triangles) go(srt_trace_kernel<true, false, true, true>);
-			else go(srt_trace_kernel<false, false, true, true>);
-		}
-	} else if (use_lds) {
-		if (count_triangles) go(srt_trace_kernel<true, true, true, false>);
-		else go(srt_trace_kernel<false, true, true, false>);
-	} else {
-		if (count_triangles) go(srt_trace_kernel<true, false, true, false>);
-		else go(srt_trace_kernel<false, false, true, false>);
-	}
+	const size_t need = scene_lds + (size_t)srt_trace_lds_floats(p.num_models > 0, p.use_bvh) * sizeof(float);
+	hipLaunchKernelGGL(pick_trace_kernel(p.num_models > 0, p.use_bvh != 0, scene_lds != 0, count_triangles), grid, block, need, (hipStream_t)stream, p);
 }
 
 void srt_launch_reduce(const ReduceParams &p, void *stream) {

@@ -78,6 +78,7 @@ struct srt_tracer {
 	DevBuf<float> running;   // float4 per pixel, carries the ordered sum across batches
 	size_t radiance_budget = 0; // bytes; 0 = pick from free HBM at first use
 	int num_cus = 0;
+	int last_waves_per_cu = 0, last_grid = 0;
 	std::vector<hipEvent_t> ev_k; // one pair per sample batch, around srt_trace_kernel alone (reduce excluded)
 	size_t ev_k_used = 0;         // events of the last srt_trace
 	float last_trace_kernel_ms = 0.f, last_reduce_ms = 0.f;
@@ -549,6 +550,15 @@ static int update_scene_impl(srt_tracer *t, const srt_shape *shapes, size_t n_sh
 		memcpy(&f, &u, 4);
 		return f;
 	};
+	// The kernel walks 64-byte BLOCKS of same-type shapes in array order (device_types.h ShapeRun): four spheres,
+	// two planes or two models each, block b at dword 16 * b. A block that is not full is
+	// filled up with records that can never be hit (r*r = -inf makes the discriminant -inf or NaN; a zero plane
+	// normal makes denom == 0, render.cl:209-211).
+	auto pad_run = [&]() {
+		if (!runs.empty() && runs.back().type == SRT_SHAPE_SPHERE)
+			while (data.size() % 16) data.insert(data.end(), {0.0f, 0.0f, 0.0f, -INFINITY});
+		while (data.size() % 16) data.push_back(0.0f);
+	};
 	for (size_t i = 0; i < n_shapes; i++) {
 		const srt_shape &s = shapes[i];
 		WinnerRec &wr = winners[i];
@@ -561,13 +571,14 @@ static int update_scene_impl(srt_tracer *t, const srt_shape *shapes, size_t n_sh
 			return fail(t, SRT_ERR_INVALID, buf);
 		}
 		if (s.type != SRT_SHAPE_SPHERE && s.type != SRT_SHAPE_PLANE && s.type != SRT_SHAPE_MODEL) continue; // ignored, as render.cl:301-366
-		if (runs.empty() || runs.back().type != s.type || runs.back().first_shape + runs.back().count != i) {
-			while (data.size() % 16) data.push_back(0.0f);
+		const uint32_t block_cap = s.type == SRT_SHAPE_SPHERE ? 4u : 2u;
+		if (runs.empty() || runs.back().type != s.type || runs.back().first_shape + runs.back().count != i || runs.back().count == block_cap) {
+			pad_run();
 			ShapeRun r;
 			r.type = s.type;
 			r.first_shape = (uint32_t)i;
 			r.count = 0;
-			r.data_off = (uint32_t)data.size();
+			r.data_off = (uint32_t)data.size(); // = 16 * block number
 			runs.push_back(r);
 		}
 		runs.back().count++;
@@ -660,15 +671,15 @@ static int update_scene_impl(srt_tracer *t, const srt_shape *shapes, size_t n_sh
 			num_models++;
 		}
 	}
-	data.resize(data.size() + 32, 0.0f); // the kernel reads whole 64-byte blocks past a run's last record
-	while (data.size() % 16) data.push_back(0.0f);
+	pad_run();
+	data.resize(data.size() + 32, 0.0f); // slack: the kernel reads whole 64-byte blocks
 	const uint64_t build_us =
 	    (uint64_t)std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - build_t0).count();
 
 	SRT_HIP(t, hipSetDevice(t->device));
 	SRT_HIP(t, hipStreamSynchronize(t->stream)); // previous launches may still read the old scene
 	SRT_HIP(t, t->shapes.reserve(n_shapes));
-	SRT_HIP(t, t->runs.reserve(runs.size()));
+	SRT_HIP(t, t->runs.reserve(runs.size() + 1)); // the kernel fetches one header ahead
 	SRT_HIP(t, t->run_data.reserve(data.size()));
 	SRT_HIP(t, t->winners.reserve(n_shapes));
 	SRT_HIP(t, t->wtri_offset.reserve(n_shapes));
@@ -820,6 +831,9 @@ int srt_trace(srt_tracer *t, const srt_render_data *options) {
 	if (pixels > 0 && batch > 0) {
 		size_t fit = t->radiance_budget / (pixels * 12);
 		if (fit < 1) fit = 1;
+		// the trace kernel numbers the work-items of a launch with 32 bits
+		const size_t fit32 = (size_t)0xfffffff0u / pixels;
+		if (fit32 < fit) fit = fit32 ? fit32 : 1;
 		if (fit < batch) batch = (uint32_t)fit;
 		if (batch > 4 && (batch & 3u)) batch &= ~3u; // keep the reduce kernel's 16-byte loads aligned
 	}
@@ -837,7 +851,13 @@ int srt_trace(srt_tracer *t, const srt_render_data *options) {
 	if (n_batches > 1) SRT_HIP(t, t->running.reserve(pixels * 4));
 	p.radiance = t->radiance.ptr;
 	p.queue = t->counters.ptr + SRT_CTR_QUEUE;
-	int slots = t->num_cus * 4 * srt_trace_waves_per_simd(t->num_models > 0, t->bvh_active);
+	int per_cu = srt_trace_resident_waves_per_cu(p, t->count_tris);
+	if (const char *env = getenv("SRT_WAVES_PER_CU")) { // experiments only
+		const int v = atoi(env);
+		if (v > 0 && v < per_cu) per_cu = v;
+	}
+	t->last_waves_per_cu = per_cu;
+	int slots = t->num_cus * per_cu;
 	if (slots > SRT_WAVE_CTR_SLOTS) slots = SRT_WAVE_CTR_SLOTS; // one counter line per persistent wave
 
 	ReduceParams rp;
@@ -893,6 +913,7 @@ int srt_trace(srt_tracer *t, const srt_render_data *options) {
 		const int num_waves = (int)(waves_needed < slots_b ? waves_needed : slots_b);
 		SRT_HIP(t, hipMemsetAsync(p.queue, 0, sizeof(unsigned long long), t->stream));
 		SRT_HIP(t, hipEventRecord(t->ev_k[2 * b], t->stream));
+		t->last_grid = num_waves;
 		srt_launch_trace(p, t->count_tris, num_waves, t->stream);
 		SRT_HIP(t, hipGetLastError());
 		SRT_HIP(t, hipEventRecord(t->ev_k[2 * b + 1], t->stream));
@@ -1170,6 +1191,30 @@ int srt_bvh_build_host(const srt_shape *model, const srt_triangle *triangles, si
 int srt_acceleration_info(const srt_tracer *t, uint64_t out[7]) {
 	if (!t || !out) return SRT_ERR_INVALID;
 	for (int i = 0; i < 7; i++) out[i] = t->bvh_active ? t->bvh_info[i] : 0;
+	return SRT_OK;
+}
+
+/* diagnostics: sums of the eight per-wave counter slots since the last reset (slot 5 = stragglers that stored their
+ * radiance themselves + (staging buffers written out with paths still under way << 40), 6 = wave iterations,
+ * 7 = SHADE phases) */
+int srt_debug_counters(srt_tracer *t, uint64_t out[18]) {
+	if (!t || !out) return SRT_ERR_INVALID;
+	SRT_HIP(t, hipSetDevice(t->device));
+	std::vector<unsigned long long> w;
+	try {
+		w.resize((size_t)SRT_WAVE_CTR_SLOTS * SRT_WAVE_CTR_STRIDE);
+	} catch (...) {
+		return fail(t, SRT_ERR_INVALID, "out of host memory");
+	}
+	SRT_HIP(t, hipMemcpyAsync(w.data(), t->wave_counters.ptr, w.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, t->stream));
+	SRT_HIP(t, hipStreamSynchronize(t->stream));
+	for (int k = 0; k < 18; k++) out[k] = 0;
+	for (size_t i = 0; i < (size_t)SRT_WAVE_CTR_SLOTS; i++) {
+		for (int k = 0; k < 8; k++) out[k] += w[i * SRT_WAVE_CTR_STRIDE + k];
+		for (int k = 8; k < 16; k++) out[k + 2] += w[i * SRT_WAVE_CTR_STRIDE + k]; // phase clocks of -DSRT_PHASE_CLOCK builds
+	}
+	out[8] = (uint64_t)t->last_waves_per_cu;
+	out[9] = (uint64_t)t->last_grid;
 	return SRT_OK;
 }
 

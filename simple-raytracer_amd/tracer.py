@@ -27,7 +27,7 @@ ABI_SYMBOLS = [
     "srt_get_counters", "srt_set_count_triangles", "srt_reset_counters", "srt_last_kernel_ms", "srt_last_trace_kernel_ms",
     "srt_device_buffers", "srt_bind_canvas", "srt_bind_stream", "srt_set_partition",
     "srt_partition_owned_rows", "srt_partition_padded_rows", "srt_partition_global_row",
-    "srt_partition_unpermute", "srt_selftest_math", "srt_version", "srt_set_acceleration", "srt_acceleration_info", "srt_bvh_build_host",
+    "srt_partition_unpermute", "srt_selftest_math", "srt_version", "srt_set_acceleration", "srt_acceleration_info", "srt_bvh_build_host", "srt_debug_counters",
 ]
 
 ACCEL_NONE, ACCEL_BVH = 0, 1
@@ -224,6 +224,15 @@ class Tracer:
         c = Counters()
         self._check(self.lib.srt_get_counters(self._h, C.byref(c)))
         return c.as_dict()
+
+    def debug_counters(self):
+        out = (C.c_uint64 * 18)()
+        self.lib.srt_debug_counters.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
+        self._check(self.lib.srt_debug_counters(self._h, out))
+        v = [int(x) for x in out]
+        return {"rays": v[0], "sky": v[1], "paths": v[2], "orphans": v[5] & ((1 << 40) - 1), "evictions": v[5] >> 40,
+                "iterations": v[6], "shade_phases": v[7], "waves_per_cu": v[8], "grid": v[9],
+                "phase_cycles": dict(zip(("extend", "ring", "shade", "park", "deliver", "refill", "head", "kernel"), v[10:18]))}
 
     def reset_counters(self):
         self._check(self.lib.srt_reset_counters(self._h))

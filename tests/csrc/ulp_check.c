@@ -132,6 +132,39 @@ int main(int argc, char **argv) {
 		}
 		printf("atan2pi %.4f 40000000\n", worst);
 	}
+	/* normalize: every component against v / |v| in double; bound 2 + n = 5 ulp. Random directions with component
+	 * magnitudes from 1e-6 to 1e3 (the kernel normalises Gaussian triples, camera rays and mixes of unit vectors),
+	 * plus rsqrt alone on every stride-th float in [2^-100, 2^100] */
+	{
+		double worst = 0;
+		for (int i = 0; i < 20000000; i++) {
+			float v[3], o[3];
+			for (int c = 0; c < 3; c++) {
+				float m = ((float)rnd() / 4294967296.0f) * 2.0f - 1.0f;
+				int e = (int)(rnd() % 31u) - 20;
+				v[c] = ldexpf(m, (i & 3) ? 0 : e);
+			}
+			dm_normalize3(v, o);
+			double len = sqrt((double)v[0] * v[0] + (double)v[1] * v[1] + (double)v[2] * v[2]);
+			if (len == 0.0) continue;
+			for (int c = 0; c < 3; c++) {
+				double e = ulp_err(o[c], (double)v[c] / len);
+				if (e > worst) worst = e;
+			}
+		}
+		printf("normalize %.4f 20000000\n", worst);
+		worst = 0;
+		unsigned long n = 0;
+		uint32_t lo = dm_f2u(0x1p-100f), hi = dm_f2u(0x1p100f);
+#pragma omp parallel for reduction(max : worst) reduction(+ : n) schedule(static)
+		for (long b = lo; b <= (long)hi; b += stride) {
+			float x = dm_u2f((uint32_t)b);
+			double e = ulp_err(dm_rsqrtf(x), 1.0 / sqrt((double)x));
+			if (e > worst) worst = e;
+			n++;
+		}
+		printf("rsqrt %.4f %lu\n", worst, n);
+	}
 	/* special values */
 	{
 		int bad = 0;
@@ -146,6 +179,14 @@ int main(int argc, char **argv) {
 		bad += !(dm_powf(2.0f, 3.0f) == 8.0f);
 		bad += !(dm_powf(-2.0f, 3.0f) == -8.0f);
 		bad += !(isnan(dm_powf(-2.0f, 0.5f)));
+		{
+			float zero[3] = {0.0f, 0.0f, 0.0f}, o[3];
+			dm_normalize3(zero, o); /* OpenCL: normalize of the zero vector is the zero vector */
+			bad += !(o[0] == 0.0f && o[1] == 0.0f && o[2] == 0.0f);
+			float unit[3] = {0.0f, -3.0f, 0.0f};
+			dm_normalize3(unit, o);
+			bad += !(o[0] == 0.0f && fabsf(o[1] + 1.0f) < 3e-7f && o[2] == 0.0f);
+		}
 		bad += !(dm_atan2pif(0.0f, 1.0f) == 0.0f);
 		bad += !(dm_atan2pif(0.0f, -1.0f) == 1.0f);
 		bad += !(dm_atan2pif(-0.0f, -1.0f) == -1.0f);

@@ -38,6 +38,9 @@ def gen_cases(ref, sky):
         def fn(rd, canvas, case=case):
             return ref.render(rd, case["sd"], case["shapes"], case["tris"], case["mats"], sky, canvas=canvas, nthreads=8)
         canvas = C.render_case(fn, case, sky)
+        # An OpenCL float3 occupies 16 bytes and the 4th lane is unspecified (the x86-64 build of render.cl leaves
+        # whatever its vector registers held there): only x, y, z are results. Stored as 0, like a cleared canvas.
+        canvas[..., 3] = 0.0
         argb = ref.average(len(case["frames"]), canvas)
         rd = case["rd"]
         w, h, ns = int(rd["width"]), int(rd["height"]), int(rd["num_samples"])

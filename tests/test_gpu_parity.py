@@ -204,13 +204,13 @@ def test_device_math_equals_host_math(T, oracle):
     assert full[1] == 0, f"log_unit differs from dm_logf on {full[1]} RNG outputs"
     assert full[2] == 0, f"cos_2pi differs from dm_cosf on {full[2]} RNG outputs"
     assert full[8] == 0, f"div3 differs from IEEE division on {full[8]} of 2^32 random operand sets"
-    assert full[9] == 0, f"normalize3 differs from a / sqrt(dot(a, a)) on {full[9]} of 2^32 random vectors"
     assert full[10] == 0, f"unguarded Box-Muller sqrt differs from IEEE sqrt on {full[10]} RNG outputs"
     assert full[11] == 0, f"folding the 2^-32 RNG scaling changes log or theta on {full[11]} RNG outputs"
     dev = t.selftest_math(61)
     host = oracle.math_checksums(61)
-    assert dev[:3] == [0, 0, 0] and dev[8:12] == [0, 0, 0, 0]
+    assert dev[:3] == [0, 0, 0] and dev[8] == 0 and dev[10:12] == [0, 0]
     assert dev[3:8] == host[3:8], (dev, host)
+    assert dev[9] == host[0], "the built-in normalize (division-free rsqrt) differs between gfx950 and x86-64"
     t.close()
 
 

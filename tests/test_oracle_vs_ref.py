@@ -12,7 +12,8 @@ def _both(oracle, ref, scene, sky, w, h, spp, **kw):
     sd = R.scene_data(len(shapes))
     a = oracle.render(rd, sd, shapes, tris, mats, sky, nthreads=4)
     b = ref.render(rd, sd, shapes, tris, mats, sky, nthreads=4)
-    return a, b
+    # x, y, z only: the 4th lane of an OpenCL float3 is unspecified and the reference build leaves register garbage in it
+    return a[..., :3], b[..., :3]
 
 
 def test_sphere_scene_config0_slice(oracle, ref, sky):
@@ -33,6 +34,7 @@ def test_random_time_seeds(oracle, ref, sky):
 
 def test_average_bytes(oracle, ref, sky):
     a, _ = _both(oracle, ref, S.sphere_scene(), sky, 64, 48, 4)
+    a = np.concatenate([a, np.zeros_like(a[..., :1])], axis=-1)
     a[0, 0, :3] = np.nan  # NaN poisoning must resolve to byte 0, not crash
     a[0, 1, :3] = (1e9, 0.0, -1.0)
     for steps in (1, 3):

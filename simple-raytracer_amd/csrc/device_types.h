@@ -10,21 +10,26 @@
 /* Scene data for the wave-uniform intersection loop. Every lane of a wave tests the SAME
  * shape at the same time (array order, render.cl:299), so these records are fetched with
  * scalar loads into SGPRs, not staged per lane. Consecutive shapes of one type are packed into
- * 64-byte BLOCKS, walked in array order (so the first-of-equal-t rule of render.cl:306 is kept);
- * block b lives at dword 16 * b of the packed array and has a 16-byte header (ShapeRun) in a
- * parallel array, so the kernel can fetch header and data of block b + 1 while it tests block b:
+ * 64-byte BLOCKS, walked in array order (so the first-of-equal-t rule of render.cl:306 is kept):
  *   sphere: 4 dwords  {cx, cy, cz, r*r}                    -> 4 spheres per block
  *   plane : 8 dwords  {px, py, pz, 0, nx, ny, nz, 0}       -> 2 planes per block
  *   model : 8 dwords  {min.x, min.y, min.z, first_wtri(bits), max.x, max.y, max.z, count(bits)} -> 2 per block
  *           (with a BVH: the root node's index in place of first_wtri)
- * A block that is not full ends in records that cannot be hit (srt_abi.hip). */
-struct ShapeRun {
+ * A block that is not full ends in records that cannot be hit (srt_abi.hip). Block b lives at
+ * dword 16 * b of the packed array. Three consecutive blocks form a GROUP with one 16-byte header
+ * (BlockGroup): the kernel issues the header load and the three 64-byte block loads together and
+ * waits once -- a 7-shape scene is one group, i.e. one scalar-memory round trip per path segment. */
+struct ShapeRun { /* host side only: a block while it is being packed */
 	int32_t type;
 	uint32_t first_shape;
 	uint32_t count;
 	uint32_t data_off;
 };
-static_assert(sizeof(ShapeRun) == 16, "ShapeRun 16 B");
+struct BlockGroup {
+	uint32_t code;     /* byte k = block k of the group: (shape type + 1) | shapes in the block << 2; 0 = no block */
+	uint32_t first[3]; /* index of each block's first shape */
+};
+static_assert(sizeof(BlockGroup) == 16, "BlockGroup 16 B");
 
 /* Per-shape record for the per-lane winner lookup after the loop (staged in LDS):
  *   sphere: v = centre, w = radius; plane: v = normal; model: unused (rare path reads
@@ -71,7 +76,7 @@ enum { SRT_CTR_RAYS = 0, SRT_CTR_SKY, SRT_CTR_TRI, SRT_CTR_TRI_PASS_U, SRT_CTR_N
 struct TraceParams {
 	srt_render_data rd;
 	srt_scene_data sd;
-	const ShapeRun *runs;
+	const BlockGroup *runs; /* group headers, num_runs of them */
 	const float *run_data;
 	const WinnerRec *winners;
 	int32_t num_runs;

@@ -678,7 +678,7 @@ __global__ __launch_bounds__(64, USE_BVH ? SRT_TRACE_WAVES_PER_SIMD_BVH : HAS_MO
 	const int ns = p.rd.num_samples;
 	const int nb = p.rd.num_bounces;
 	const int n_shapes = p.sd.num_shapes;
-	const ShapeRun *__restrict__ runs = p.runs;
+	const BlockGroup *__restrict__ runs = p.runs;
 	const float *__restrict__ run_data = p.run_data;
 	const float *__restrict__ wtris = p.wtris;
 
@@ -727,7 +727,9 @@ __global__ __launch_bounds__(64, USE_BVH ? SRT_TRACE_WAVES_PER_SIMD_BVH : HAS_MO
 	bool active = false;   // the lane holds a ray that awaits closest_intersection
 	// rays / sky / paths are counted per WAVE with popcounts of the exec mask (scalar adds, no
 	// VGPRs); only the instrumented triangle counters stay per lane.
-	unsigned long long w_rays = 0, w_sky = 0, w_paths = 0, w_orphans = 0, w_evict = 0, w_iter = 0, w_shade = 0;
+	// (paths and sky lookups of a wave stay below the launch's 2^32 items; iterations are diagnostics)
+	unsigned long long w_rays = 0;
+	uint32_t w_sky = 0, w_paths = 0, w_orphans = 0, w_evict = 0, w_iter = 0, w_shade = 0;
 	uint32_t n_tri = 0, n_tri_u = 0;
 	uint32_t idle_spins = 0;
 
@@ -752,21 +754,17 @@ __global__ __launch_bounds__(64, USE_BVH ? SRT_TRACE_WAVES_PER_SIMD_BVH : HAS_MO
 					// Blocks of same-type shapes in array order; header and data of the NEXT block are fetched (scalar
 					// loads, one allocated past the end) before this one is tested, so only the first block's load
 					// latency is exposed per segment.
-					const int n_blocks = p.num_runs;
-					float hd[4];
-					ld_uniform<4, 16>(reinterpret_cast<const float *>(runs), hd);
-					Blk16 b = ld_blk16(run_data);
-					for (int r = 0; r < n_blocks; r++) {
-						float hn[4];
-						ld_uniform<4, 16>(reinterpret_cast<const float *>(runs + r + 1), hn);
-						const Blk16 bn = ld_blk16(run_data + 16 * (r + 1));
-						const int type = (int32_t)f2u(hd[0]);
-						const int base = (int)f2u(hd[1]);
-						if (type == SRT_SHAPE_SPHERE) {
+					// Groups of three 64-byte blocks of same-type shapes, in array order (device_types.h). The header and
+					// the three blocks of a group are fetched with four scalar loads issued together: one scalar-memory
+					// round trip per group (a 7-shape scene is one group). The mesh kernels, whose triangle loops need
+					// the scalar registers, fetch the blocks of a group one by one instead.
+					auto test_block = [&](const Blk16 &b, uint32_t code, int base) {
+						const uint32_t type1 = code & 3u; // shape type + 1; 0 = no block
+						if (type1 == SRT_SHAPE_SPHERE + 1u) {
 							test_spheres4(b, org, dir, base, tmin, best);
-						} else if (type == SRT_SHAPE_PLANE) {
+						} else if (type1 == SRT_SHAPE_PLANE + 1u) {
 							test_planes2(b, org, dir, base, tmin, best);
-						} else if (HAS_MODELS && type == SRT_SHAPE_MODEL) {
+						} else if (HAS_MODELS && type1 == SRT_SHAPE_MODEL + 1u) {
 							// the model's own box first, exactly as the reference (render.cl:316-323), then its triangles
 							if (test_aabb(b.v[0], b.v[1], b.v[2], b.v[4], b.v[5], b.v[6], org, inv, tmin)) {
 								if (USE_BVH) {
@@ -777,7 +775,7 @@ __global__ __launch_bounds__(64, USE_BVH ? SRT_TRACE_WAVES_PER_SIMD_BVH : HAS_MO
 									test_triangles<COUNT_TRIS>(wtris, f2u(b.v[3]), f2u(b.v[7]), org, dir, base, tmin, best, best_tri, n_tri_u);
 								}
 							}
-							if (f2u(hd[2]) > 1u && test_aabb(b.v[8], b.v[9], b.v[10], b.v[12], b.v[13], b.v[14], org, inv, tmin)) {
+							if ((code >> 2) > 1u && test_aabb(b.v[8], b.v[9], b.v[10], b.v[12], b.v[13], b.v[14], org, inv, tmin)) {
 								if (USE_BVH) {
 									if (f2u(b.v[15]) != 0u)
 										walk_bvh<COUNT_TRIS>(p.bvh_nodes, p.bvh_tris, f2u(b.v[11]), org, dir, base + 1, tmin, best, best_tri, best_j, n_tri, n_tri_u);
@@ -787,8 +785,23 @@ __global__ __launch_bounds__(64, USE_BVH ? SRT_TRACE_WAVES_PER_SIMD_BVH : HAS_MO
 								}
 							}
 						}
-						hd[0] = hn[0], hd[1] = hn[1], hd[2] = hn[2], hd[3] = hn[3];
-						b = bn;
+					};
+					const int n_groups = p.num_runs;
+					for (int g = 0; g < n_groups; g++) {
+						float gh[4];
+						ld_uniform<4, 16>(reinterpret_cast<const float *>(runs + g), gh);
+						const uint32_t code = f2u(gh[0]);
+						const float *__restrict__ gd = run_data + 48 * g;
+						if (!HAS_MODELS) {
+							const Blk16 b0 = ld_blk16(gd), b1 = ld_blk16(gd + 16), b2 = ld_blk16(gd + 32);
+							test_block(b0, code & 255u, (int)f2u(gh[1]));
+							test_block(b1, (code >> 8) & 255u, (int)f2u(gh[2]));
+							test_block(b2, (code >> 16) & 255u, (int)f2u(gh[3]));
+						} else {
+							test_block(ld_blk16(gd), code & 255u, (int)f2u(gh[1]));
+							if ((code >> 8) & 255u) test_block(ld_blk16(gd + 16), (code >> 8) & 255u, (int)f2u(gh[2]));
+							if ((code >> 16) & 255u) test_block(ld_blk16(gd + 32), (code >> 16) & 255u, (int)f2u(gh[3]));
+						}
 					}
 					// a shape without a material counts as a miss (render.cl:404: material_index >= 0)
 					int material_index = -1;
@@ -996,7 +1009,7 @@ __global__ __launch_bounds__(64, USE_BVH ? SRT_TRACE_WAVES_PER_SIMD_BVH : HAS_MO
 			if (fin) deliver<SUB>(st, stage, p.radiance, item, color, f0, f1);
 			const uint32_t n0 = (uint32_t)__popcll(__ballot(f0)), n1 = (uint32_t)__popcll(__ballot(f1));
 			st.pend0 -= n0, st.pend1 -= n1;
-			w_orphans += (unsigned long long)__popcll(__ballot(fin)) - n0 - n1;
+			w_orphans += (uint32_t)__popcll(__ballot(fin)) - n0 - n1;
 		}
 
 		SRT_CLK(4);
@@ -1123,7 +1136,7 @@ __global__ __launch_bounds__(64, USE_BVH ? SRT_TRACE_WAVES_PER_SIMD_BVH : HAS_MO
 			w[3] += t3;
 			w[4] += t4;
 		}
-		w[5] += w_orphans + (w_evict << 40); // diagnostics (srt_debug_counters)
+		w[5] += (unsigned long long)w_orphans + ((unsigned long long)w_evict << 40); // diagnostics (srt_debug_counters)
 		w[6] += w_iter;
 		w[7] += w_shade;
 #ifdef SRT_PHASE_CLOCK

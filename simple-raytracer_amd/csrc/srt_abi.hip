@@ -55,7 +55,7 @@ struct srt_tracer {
 	size_t canvas_bytes = 0; // of the buffer in use
 	DevBuf<uint8_t> argb;
 	DevBuf<srt_shape> shapes;
-	DevBuf<ShapeRun> runs;
+	DevBuf<BlockGroup> runs; // group headers of the packed shape blocks
 	DevBuf<float> run_data;
 	DevBuf<WinnerRec> winners;
 	int num_runs = 0;
@@ -672,14 +672,22 @@ static int update_scene_impl(srt_tracer *t, const srt_shape *shapes, size_t n_sh
 		}
 	}
 	pad_run();
-	data.resize(data.size() + 32, 0.0f); // slack: the kernel reads whole 64-byte blocks
+	// group headers: three blocks each (device_types.h BlockGroup); the data of a last, partial group is zero-filled
+	std::vector<BlockGroup> groups((runs.size() + 2) / 3);
+	for (size_t b = 0; b < runs.size(); b++) {
+		BlockGroup &g = groups[b / 3];
+		if (b % 3 == 0) memset(&g, 0, sizeof g);
+		g.code |= (((uint32_t)runs[b].type + 1u) | (runs[b].count << 2)) << (8 * (b % 3));
+		g.first[b % 3] = runs[b].first_shape;
+	}
+	data.resize(groups.size() * 48 + 16, 0.0f);
 	const uint64_t build_us =
 	    (uint64_t)std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - build_t0).count();
 
 	SRT_HIP(t, hipSetDevice(t->device));
 	SRT_HIP(t, hipStreamSynchronize(t->stream)); // previous launches may still read the old scene
 	SRT_HIP(t, t->shapes.reserve(n_shapes));
-	SRT_HIP(t, t->runs.reserve(runs.size() + 1)); // the kernel fetches one header ahead
+	SRT_HIP(t, t->runs.reserve(groups.size()));
 	SRT_HIP(t, t->run_data.reserve(data.size()));
 	SRT_HIP(t, t->winners.reserve(n_shapes));
 	SRT_HIP(t, t->wtri_offset.reserve(n_shapes));
@@ -701,8 +709,8 @@ static int update_scene_impl(srt_tracer *t, const srt_shape *shapes, size_t n_sh
 		SRT_HIP(t, hipMemcpyAsync(t->winners.ptr, winners.data(), n_shapes * sizeof(WinnerRec), hipMemcpyHostToDevice, t->stream));
 		SRT_HIP(t, hipMemcpyAsync(t->wtri_offset.ptr, offs.data(), n_shapes * sizeof(uint32_t), hipMemcpyHostToDevice, t->stream));
 	}
-	if (!runs.empty())
-		SRT_HIP(t, hipMemcpyAsync(t->runs.ptr, runs.data(), runs.size() * sizeof(ShapeRun), hipMemcpyHostToDevice, t->stream));
+	if (!groups.empty())
+		SRT_HIP(t, hipMemcpyAsync(t->runs.ptr, groups.data(), groups.size() * sizeof(BlockGroup), hipMemcpyHostToDevice, t->stream));
 	SRT_HIP(t, hipMemcpyAsync(t->run_data.ptr, data.data(), data.size() * sizeof(float), hipMemcpyHostToDevice, t->stream));
 	if (n_triangles)
 		SRT_HIP(t, hipMemcpyAsync(t->triangles.ptr, triangles, n_triangles * sizeof(srt_triangle), hipMemcpyHostToDevice, t->stream));
@@ -757,7 +765,7 @@ static int update_scene_impl(srt_tracer *t, const srt_shape *shapes, size_t n_sh
 		for (const auto &pl : plan) next_cache.push_back(std::move(pl.first ? t->bvh_cache->entries[pl.second] : fresh[pl.second]));
 		t->bvh_cache->entries = std::move(next_cache);
 	}
-	t->num_runs = (int)runs.size();
+	t->num_runs = (int)groups.size();
 	t->num_materials = n_materials;
 	t->scene_set = true;
 	return SRT_OK;

@@ -191,6 +191,64 @@ int srt_partition_global_row(int height, int rank, int world, int rows_per_block
 int srt_partition_unpermute(const void *gathered, void *image, int height, int world, int rows_per_block,
                             size_t row_bytes);
 
+/* ---- collecting a partitioned frame over RCCL / xGMI (new) ----------------------- */
+
+/* One process per GPU: every rank owns a handle with srt_set_partition(rank, world, ...). Any one
+ * rank calls srt_comm_unique_id and ships the 128 bytes to the others by whatever channel the host
+ * program has (torch.distributed broadcast, MPI, a file); every rank then calls srt_comm_init
+ * (collective: it returns when all ranks have joined). RCCL is loaded on first use. */
+#define SRT_COMM_ID_BYTES 128
+int srt_comm_unique_id(void *id_out);
+int srt_comm_init(srt_tracer *t, const void *id, int rank, int world);
+/* The ONE collective of the path, enqueued on the handle's stream after srt_trace: ncclGather of the
+ * packed canvases (padded_rows * width float4 per rank) to `root`, where a kernel puts the rows back in
+ * image order. Collective: every rank calls it. */
+int srt_gather(srt_tracer *t, int root);
+/* On the root, after srt_gather: the `average` kernel over the whole gathered image (asynchronous);
+ * device pointers of the gathered canvas (height*width float4) and its resolved image; blocking
+ * read-back of either (NULL = skip). */
+int srt_resolve_gathered(srt_tracer *t, uint32_t ticks_stopped);
+int srt_gathered_buffers(srt_tracer *t, void **canvas, void **argb);
+int srt_read_gathered(srt_tracer *t, float *canvas_out, uint8_t *argb_out);
+/* The root's unpermute step alone, on caller-owned device buffers (gathered: world x padded_rows x width
+ * float4, rank-major; image: height x width float4); synchronous. For callers that gather by other
+ * means, and for tests. */
+int srt_unpermute_device(const void *gathered, void *image, int width, int height, int world, int rows_per_block);
+
+/* One process driving several GPUs -- what a front-end that keeps the reference's single `Tracer`
+ * object needs (host/tracer.hpp: Tracer(width, height, n_devices)). The group owns one handle per
+ * device (devices == NULL: 0 .. n_devices-1), partitioned in interleaved blocks of rows_per_block
+ * rows, and one communicator (ncclCommInitAll). Scene, skybox and options are replicated;
+ * srt_group_render = trace on every device, one gather to the group's first device, resolve there,
+ * blocking read-back of width*height*4 bytes: the image equals the single-device one bit for bit. */
+typedef struct srt_group srt_group;
+int srt_group_create(int width, int height, int n_devices, const int *devices, int rows_per_block, srt_group **out);
+void srt_group_destroy(srt_group *g);
+const char *srt_group_last_error(const srt_group *g);
+int srt_group_size(const srt_group *g);
+srt_tracer *srt_group_tracer(srt_group *g, int i);
+int srt_group_set_skybox(srt_group *g, const float *rgba, int width, int height);
+int srt_group_set_acceleration(srt_group *g, int mode);
+int srt_group_update_scene(srt_group *g, const srt_shape *shapes, size_t n_shapes, const srt_triangle *triangles, size_t n_triangles,
+                           const srt_material *materials, size_t n_materials, const srt_scene_data *scene);
+int srt_group_clear_canvas(srt_group *g);
+int srt_group_trace_and_gather(srt_group *g, const srt_render_data *options); /* asynchronous */
+int srt_group_render(srt_group *g, const srt_render_data *options, uint32_t ticks_stopped, uint8_t *argb_out);
+int srt_group_read_canvas(srt_group *g, float *rgba_out); /* the gathered canvas, height*width float4 */
+int srt_group_get_counters(srt_group *g, srt_counters *out); /* summed over the devices */
+
+/* ---- frame pipeline for the interactive loop (new; src/main.cpp:277-337) ----------- */
+
+/* srt_render with the read-back of frame N overlapped with the trace of frame N+1: the call enqueues
+ * frame N (trace, resolve into one of two device images, copy to pinned host memory on a second
+ * stream) and hands out frame N-1, waiting only for THAT frame's copy. *frame_delivered = index of the
+ * frame written to argb_out (0, 1, ...), or -1 on the first call (argb_out untouched). Frames are the
+ * same bytes srt_render would have produced, one call later. srt_pipeline_flush waits for and hands out
+ * the newest frame still in flight (-1: none). */
+int srt_render_pipelined(srt_tracer *t, const srt_render_data *options, uint32_t ticks_stopped, uint8_t *argb_out,
+                         long long *frame_delivered);
+int srt_pipeline_flush(srt_tracer *t, uint8_t *argb_out, long long *frame_delivered);
+
 /* Device self-test of the deterministic math (tests only). Walks r = 0, stride, ... over
  * all 2^32 RNG outputs: out[0..2] = mismatch counts of the kernel-local sqrt / log / cos
  * specialisations against their generic definitions (must be 0); out[3..7] = sums of the

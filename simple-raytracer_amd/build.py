@@ -23,8 +23,8 @@ PKG = Path(__file__).resolve().parent
 CSRC = PKG / "csrc"
 LIBDIR = PKG / "lib"
 LIB = LIBDIR / "libsrt_hip.so"
-SOURCES = ["kernels.hip", "srt_abi.hip"]
-HEADERS = ["detmath.h", "device_types.h", "../../include/srt_abi.h", "../../include/srt_types.h"]
+SOURCES = ["kernels.hip", "srt_abi.hip", "srt_collect.hip"]
+HEADERS = ["detmath.h", "device_types.h", "srt_internal.h", "../../include/srt_abi.h", "../../include/srt_types.h"]
 ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize", "-fPIC", "-fno-gpu-rdc", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function",
          "-Rpass-analysis=kernel-resource-usage"]
@@ -90,7 +90,7 @@ def build_variant(name, extra_flags):
     """A/B experiments: the same sources with extra -D flags -> lib/variants/<name>/libsrt_hip.so."""
     out = LIBDIR / "variants" / name
     out.mkdir(parents=True, exist_ok=True)
-    cmd = [hipcc(), *FLAGS, *extra_flags, "-shared", "-o", str(out / "libsrt_hip.so")] + [str(CSRC / s) for s in SOURCES]
+    cmd = [hipcc(), *FLAGS, *extra_flags, "-shared", "-o", str(out / "libsrt_hip.so")] + [str(CSRC / s) for s in SOURCES] + ["-ldl"]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError("hipcc failed:\n" + r.stdout + r.stderr)
@@ -107,7 +107,7 @@ def build_hip(force=False, verbose=False, extra_flags=()):
         if not force and not stale():  # another process built it while we waited
             return LIB
         tmp = LIBDIR / f".libsrt_hip.{os.getpid()}.so"
-        cmd = [hipcc(), *FLAGS, *extra_flags, "-shared", "-o", str(tmp)] + [str(CSRC / s) for s in SOURCES]
+        cmd = [hipcc(), *FLAGS, *extra_flags, "-shared", "-o", str(tmp)] + [str(CSRC / s) for s in SOURCES] + ["-ldl"]
         if verbose:
             print(" ".join(cmd))
         r = subprocess.run(cmd, capture_output=True, text=True)

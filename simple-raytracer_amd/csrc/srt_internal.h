@@ -1,0 +1,99 @@
+// srt_internal.h — the handle behind `srt_tracer *` and the small helpers the translation units of
+// libsrt_hip.so share (srt_abi.hip: life cycle, scene, trace; srt_collect.hip: multi-GPU collection,
+// frame pipeline). Not part of the public ABI.
+#ifndef SRT_INTERNAL_H
+#define SRT_INTERNAL_H
+
+#include <hip/hip_runtime.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/srt_abi.h"
+#include "device_types.h"
+
+template <class T>
+struct DevBuf {
+	T *ptr = nullptr;
+	size_t cap = 0; // elements
+	// "buffers only ever grow" (src/tracer.cpp:5-9)
+	hipError_t reserve(size_t n) {
+		if (n < 1) n = 1;
+		if (n <= cap) return hipSuccess;
+		if (ptr) (void)hipFree(ptr);
+		ptr = nullptr;
+		cap = 0;
+		hipError_t e = hipMalloc(reinterpret_cast<void **>(&ptr), n * sizeof(T));
+		if (e == hipSuccess) cap = n;
+		return e;
+	}
+	void release() {
+		if (ptr) (void)hipFree(ptr);
+		ptr = nullptr;
+		cap = 0;
+	}
+};
+
+struct SrtCollect; // srt_collect.hip: RCCL communicator, gathered canvases, frame pipeline
+
+struct srt_tracer {
+	int width = 0, height = 0, device = 0;
+	SrtCollect *collect = nullptr;
+	hipStream_t own_stream = nullptr, stream = nullptr;
+	DevBuf<float> canvas_own;
+	float *canvas = nullptr;
+	size_t canvas_bytes = 0; // of the buffer in use
+	DevBuf<uint8_t> argb;
+	DevBuf<srt_shape> shapes;
+	DevBuf<BlockGroup> runs; // group headers of the packed shape blocks
+	DevBuf<float> run_data;
+	DevBuf<WinnerRec> winners;
+	int num_runs = 0;
+	size_t num_materials = 0;
+	DevBuf<srt_triangle> triangles;
+	DevBuf<srt_material> materials;
+	DevBuf<float> wtris;
+	DevBuf<uint32_t> wtri_offset;
+	DevBuf<float> sky;
+	DevBuf<BvhNode> bvh_nodes;
+	DevBuf<uint32_t> bvh_order;
+	DevBuf<float> bvh_tris;
+	int accel_mode = SRT_ACCEL_NONE; // what the next srt_update_scene builds
+	bool bvh_active = false;         // the current scene's models carry BVH roots
+	uint64_t bvh_info[7] = {0, 0, 0, 0, 0, 0, 0};
+	struct BvhCache *bvh_cache = nullptr; // hierarchies of the previous srt_update_scene (see BvhCacheEntry)
+	DevBuf<unsigned long long> counters;
+	DevBuf<unsigned long long> wave_counters; // per persistent wave, summed in srt_get_counters
+	DevBuf<float> radiance;  // 3 floats per (pixel, sample) of the current batch
+	DevBuf<float> running;   // float4 per pixel, carries the ordered sum across batches
+	size_t radiance_budget = 0; // bytes; 0 = pick from free HBM at first use
+	int num_cus = 0;
+	int last_waves_per_cu = 0, last_grid = 0;
+	std::vector<hipEvent_t> ev_k; // one pair per sample batch, around srt_trace_kernel alone (reduce excluded)
+	size_t ev_k_used = 0;         // events of the last srt_trace
+	float last_trace_kernel_ms = 0.f, last_reduce_ms = 0.f;
+	int sky_w = 0, sky_h = 0;
+	srt_scene_data sd{};
+	int num_models = 0;
+	bool scene_set = false;
+	bool count_tris = false;
+	int rank = 0, world = 1, rows_per_block = 8, owned_rows = 0;
+	hipEvent_t ev_t0 = nullptr, ev_t1 = nullptr, ev_r0 = nullptr, ev_r1 = nullptr;
+	bool have_trace_ev = false, have_resolve_ev = false, have_kernel_ev = false;
+	std::string err;
+};
+
+int srt_fail(srt_tracer *t, int code, const std::string &msg); // records the text for srt_last_error (t == NULL: srt_create's)
+static inline int fail(srt_tracer *t, int code, const std::string &msg) { return srt_fail(t, code, msg); }
+
+#define SRT_HIP(t, call)                                                                              \
+	do {                                                                                              \
+		hipError_t e_ = (call);                                                                       \
+		if (e_ != hipSuccess)                                                                         \
+			return fail((t), SRT_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_));         \
+	} while (0)
+
+
+void srt_collect_release(srt_tracer *t);
+
+#endif

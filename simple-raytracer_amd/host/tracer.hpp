@@ -27,10 +27,11 @@
 
 class Tracer {
   private:
-	srt_tracer *handle = nullptr;
+	srt_tracer *handle = nullptr; // one device ...
+	srt_group *group = nullptr;   // ... or a group of devices (n_devices > 1): rows dealt in interleaved blocks, one RCCL gather per frame
 
 	void check(int rc) const {
-		if (rc != SRT_OK) throw std::runtime_error(std::string("srt: ") + srt_last_error(handle));
+		if (rc != SRT_OK) throw std::runtime_error(std::string("srt: ") + (group ? srt_group_last_error(group) : srt_last_error(handle)));
 	}
 
   public:
@@ -65,55 +66,82 @@ class Tracer {
 		cl_float3 sun_direction;
 	} scene_data;
 
-	Tracer(const int width, const int height, const int device = 0) : options(width, height), scene_data() {
-		int rc = srt_create(width, height, device, &handle);
+	/// n_devices == 1: the reference's single-device Tracer on HIP device `device`. n_devices > 1 (new): the same
+	/// interface over devices 0 .. n_devices-1 of this node; every call below fans out, render() collects the
+	/// frame with ONE ncclGather on device 0 and returns the same bytes a single device would.
+	Tracer(const int width, const int height, const int device = 0, const int n_devices = 1) : options(width, height), scene_data() {
+		int rc = n_devices > 1 ? srt_group_create(width, height, n_devices, nullptr, 8, &group) : srt_create(width, height, device, &handle);
 		if (rc != SRT_OK) throw std::runtime_error(std::string("srt_create: ") + srt_last_error(nullptr));
 	}
-	~Tracer() { srt_destroy(handle); }
+	~Tracer() {
+		srt_group_destroy(group);
+		srt_destroy(handle);
+	}
 	Tracer(const Tracer &) = delete;
 	Tracer &operator=(const Tracer &) = delete;
 
 	/// replaces the stbi_loadf + enqueue_write_image of the reference's constructor:
 	/// `rgba` = width*height RGBA32F texels, row 0 = bottom of the picture
-	void set_skybox(const float *rgba, int width, int height) { check(srt_set_skybox(handle, rgba, width, height)); }
+	void set_skybox(const float *rgba, int width, int height) {
+		check(group ? srt_group_set_skybox(group, rgba, width, height) : srt_set_skybox(handle, rgba, width, height));
+	}
 
 	void update_scene(
 		const std::vector<Shape> &shapes, const std::vector<Triangle> &triangles, const std::vector<Material> &materials
 	) {
 		static_assert(sizeof(SceneData) == sizeof(srt_scene_data), "SceneData layout");
-		check(srt_update_scene(
-			handle, reinterpret_cast<const srt_shape *>(shapes.data()), shapes.size(),
-			reinterpret_cast<const srt_triangle *>(triangles.data()), triangles.size(),
-			reinterpret_cast<const srt_material *>(materials.data()), materials.size(),
-			reinterpret_cast<const srt_scene_data *>(&scene_data)
-		));
+		const srt_shape *sh = reinterpret_cast<const srt_shape *>(shapes.data());
+		const srt_triangle *tr = reinterpret_cast<const srt_triangle *>(triangles.data());
+		const srt_material *ma = reinterpret_cast<const srt_material *>(materials.data());
+		const srt_scene_data *sd = reinterpret_cast<const srt_scene_data *>(&scene_data);
+		check(group ? srt_group_update_scene(group, sh, shapes.size(), tr, triangles.size(), ma, materials.size(), sd)
+		            : srt_update_scene(handle, sh, shapes.size(), tr, triangles.size(), ma, materials.size(), sd));
 		scene_data.num_shapes = (cl_int)shapes.size();
 	}
 
-	void clear_canvas() { check(srt_clear_canvas(handle)); }
+	void clear_canvas() { check(group ? srt_group_clear_canvas(group) : srt_clear_canvas(handle)); }
 
 	/// trace + resolve + blocking read-back of width*height*4 bytes (A,R,G,B)
 	void render(cl_uint ticks_stopped, std::vector<uint8_t> &output) {
 		static_assert(sizeof(RenderData) == sizeof(srt_render_data), "RenderData layout");
 		if (output.size() < size_t(options.width) * size_t(options.height) * 4)
 			throw std::runtime_error("Tracer::render: output must hold width*height*4 bytes");
-		check(srt_render(handle, reinterpret_cast<const srt_render_data *>(&options), ticks_stopped, output.data()));
+		const srt_render_data *rd = reinterpret_cast<const srt_render_data *>(&options);
+		check(group ? srt_group_render(group, rd, ticks_stopped, output.data()) : srt_render(handle, rd, ticks_stopped, output.data()));
+	}
+
+	/// render() for a loop that can show a frame one call late (src/main.cpp:277-337 blits `output` right after the
+	/// call): enqueues this frame and fills `output` with the PREVIOUS one, so frame N's read-back runs under frame
+	/// N+1's trace. Returns the index of the frame delivered, -1 on the first call (output untouched); finish()
+	/// hands out the last one. Same bytes as render(), one call later. Single device only.
+	long long render_pipelined(cl_uint ticks_stopped, std::vector<uint8_t> &output) {
+		if (group) throw std::runtime_error("Tracer::render_pipelined: single-device tracers only");
+		if (output.size() < size_t(options.width) * size_t(options.height) * 4)
+			throw std::runtime_error("Tracer::render_pipelined: output must hold width*height*4 bytes");
+		long long delivered = -1;
+		check(srt_render_pipelined(handle, reinterpret_cast<const srt_render_data *>(&options), ticks_stopped, output.data(), &delivered));
+		return delivered;
+	}
+	long long finish(std::vector<uint8_t> &output) {
+		long long delivered = -1;
+		if (!group) check(srt_pipeline_flush(handle, output.data(), &delivered));
+		return delivered;
 	}
 
 	// -- extras beyond the reference's interface --
 	/// SRT_ACCEL_BVH: models get a bounding-volume hierarchy at the next update_scene (the
 	/// reference's README.md:41 "future plan"); SRT_ACCEL_NONE (default) keeps the array-order scan
-	void set_acceleration(int mode) { check(srt_set_acceleration(handle, mode)); }
+	void set_acceleration(int mode) { check(group ? srt_group_set_acceleration(group, mode) : srt_set_acceleration(handle, mode)); }
 	void read_canvas(std::vector<float> &rgba) {
 		rgba.resize(size_t(options.width) * size_t(options.height) * 4);
-		check(srt_read_canvas(handle, rgba.data()));
+		check(group ? srt_group_read_canvas(group, rgba.data()) : srt_read_canvas(handle, rgba.data()));
 	}
 	srt_counters counters() {
 		srt_counters c;
-		check(srt_get_counters(handle, &c));
+		check(group ? srt_group_get_counters(group, &c) : srt_get_counters(handle, &c));
 		return c;
 	}
-	srt_tracer *native_handle() { return handle; }
+	srt_tracer *native_handle() { return group ? srt_group_tracer(group, 0) : handle; }
 };
 
 static_assert(offsetof(Tracer::RenderData, camera_to_world) == offsetof(srt_render_data, camera_to_world), "RenderData.camera_to_world");

@@ -5,7 +5,7 @@
 //
 //   srt_headless [--scene spheres|meshes|empty] [--obj f.obj]... [--stl f.stl]...
 //                [--width W --height H --spp S --bounces B --frames N --time T]
-//                [--out frame.ppm] [--dump prefix] [--parse-only] [--bvh]
+//                [--out frame.ppm] [--dump prefix] [--parse-only] [--bvh] [--gpus N] [--pipelined]
 //
 // --dump prefix writes prefix.{shapes,tris,mats,rd,sd,canvas,argb}.bin (raw records).
 // --parse-only skips everything that needs a GPU (loaders + scene construction only).
@@ -69,7 +69,8 @@ int main(int argc, char **argv) {
 	std::vector<std::string> objs, stls;
 	int width = 256, height = 256, spp = 16, bounces = 10, frames = 1;
 	unsigned time_seed = 12345;
-	bool parse_only = false, bvh = false;
+	bool parse_only = false, bvh = false, pipelined = false;
+	int gpus = 1;
 	for (int i = 1; i < argc; i++) {
 		std::string a = argv[i];
 		auto next = [&]() -> const char * {
@@ -92,9 +93,11 @@ int main(int argc, char **argv) {
 		else if (a == "--dump") dump_prefix = next();
 		else if (a == "--parse-only") parse_only = true;
 		else if (a == "--bvh") bvh = true;
+		else if (a == "--gpus") gpus = std::atoi(next());
+		else if (a == "--pipelined") pipelined = true;
 		else {
 			std::cerr << "usage: srt_headless [--scene spheres|meshes|empty] [--obj f]... [--stl f]... [--width W --height H --spp S "
-			             "--bounces B --frames N --time T] [--out f.ppm] [--dump prefix] [--parse-only] [--bvh]\n";
+			             "--bounces B --frames N --time T] [--out f.ppm] [--dump prefix] [--parse-only] [--bvh] [--gpus N] [--pipelined]\n";
 			return 2;
 		}
 	}
@@ -158,7 +161,7 @@ int main(int argc, char **argv) {
 	if (parse_only) return 0;
 
 	// ---- tracer set-up, as src/main.cpp:114-126 ----
-	Tracer tracer(width, height);
+	Tracer tracer(width, height, 0, gpus); // --gpus N: one Tracer over N devices (rows split, one RCCL gather per frame)
 	if (bvh) tracer.set_acceleration(SRT_ACCEL_BVH);
 	tracer.options.num_samples = spp;
 	tracer.options.num_bounces = bounces;
@@ -190,9 +193,11 @@ int main(int argc, char **argv) {
 		options.camera_to_world = camera_to_world;
 		options.time = time_seed + 7919u * (unsigned)frame;
 		options.tick = (unsigned)frame;
-		tracer.render(time_not_moved, pixels);
+		if (pipelined) tracer.render_pipelined(time_not_moved, pixels); // delivers the previous frame
+		else tracer.render(time_not_moved, pixels);
 		time_not_moved++;
 	}
+	if (pipelined) tracer.finish(pixels);
 	double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
 	srt_counters c = tracer.counters();
 	std::printf("%d frame(s) %dx%d x %d spp: %.3f s, %.1f Mray/s, %llu NaN pixels\n", frames, width, height, spp, secs,

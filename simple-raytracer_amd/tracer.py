@@ -28,6 +28,10 @@ ABI_SYMBOLS = [
     "srt_device_buffers", "srt_bind_canvas", "srt_bind_stream", "srt_set_partition",
     "srt_partition_owned_rows", "srt_partition_padded_rows", "srt_partition_global_row",
     "srt_partition_unpermute", "srt_selftest_math", "srt_version", "srt_set_acceleration", "srt_acceleration_info", "srt_bvh_build_host", "srt_debug_counters",
+    "srt_comm_unique_id", "srt_comm_init", "srt_gather", "srt_resolve_gathered", "srt_gathered_buffers", "srt_read_gathered",
+    "srt_group_create", "srt_group_destroy", "srt_group_last_error", "srt_group_size", "srt_group_tracer", "srt_group_set_skybox",
+    "srt_group_set_acceleration", "srt_group_update_scene", "srt_group_clear_canvas", "srt_group_trace_and_gather", "srt_group_render",
+    "srt_group_read_canvas", "srt_group_get_counters", "srt_render_pipelined", "srt_pipeline_flush", "srt_unpermute_device",
 ]
 
 ACCEL_NONE, ACCEL_BVH = 0, 1
@@ -119,6 +123,31 @@ def load_library():
         lib.srt_set_acceleration.argtypes = [vp, i]
         lib.srt_acceleration_info.argtypes = [vp, C.POINTER(C.c_uint64)]
         lib.srt_bvh_build_host.argtypes = [vp, vp, sz, vp, sz, vp, sz, C.POINTER(sz)]
+    if hasattr(lib, "srt_gather"):
+        lib.srt_comm_unique_id.argtypes = [vp]
+        lib.srt_comm_init.argtypes = [vp, vp, i, i]
+        lib.srt_gather.argtypes = [vp, i]
+        lib.srt_resolve_gathered.argtypes = [vp, C.c_uint32]
+        lib.srt_gathered_buffers.argtypes = [vp, C.POINTER(vp), C.POINTER(vp)]
+        lib.srt_read_gathered.argtypes = [vp, vp, vp]
+        lib.srt_group_create.argtypes = [i, i, i, vp, i, C.POINTER(vp)]
+        lib.srt_group_destroy.argtypes = [vp]
+        lib.srt_group_destroy.restype = None
+        lib.srt_group_last_error.argtypes = [vp]
+        lib.srt_group_last_error.restype = C.c_char_p
+        lib.srt_group_size.argtypes = [vp]
+        lib.srt_group_tracer.argtypes = [vp, i]
+        lib.srt_group_tracer.restype = vp
+        lib.srt_group_set_skybox.argtypes = [vp, vp, i, i]
+        lib.srt_group_set_acceleration.argtypes = [vp, i]
+        lib.srt_group_update_scene.argtypes = [vp, vp, sz, vp, sz, vp, sz, vp]
+        lib.srt_group_clear_canvas.argtypes = [vp]
+        lib.srt_group_trace_and_gather.argtypes = [vp, vp]
+        lib.srt_group_render.argtypes = [vp, vp, C.c_uint32, vp]
+        lib.srt_group_read_canvas.argtypes = [vp, vp]
+        lib.srt_group_get_counters.argtypes = [vp, C.POINTER(Counters)]
+        lib.srt_render_pipelined.argtypes = [vp, vp, C.c_uint32, vp, C.POINTER(C.c_longlong)]
+        lib.srt_pipeline_flush.argtypes = [vp, vp, C.POINTER(C.c_longlong)]
     _lib = lib
     return lib
 
@@ -275,9 +304,120 @@ class Tracer:
     def bind_stream(self, hip_stream):
         self._check(self.lib.srt_bind_stream(self._h, C.c_void_p(hip_stream)))
 
+    # -- collecting a partitioned frame over RCCL (one process per GPU) --
+    @staticmethod
+    def comm_unique_id():
+        """128 bytes for srt_comm_init; made by ONE rank and shipped to all others by the caller."""
+        buf = C.create_string_buffer(128)
+        if load_library().srt_comm_unique_id(buf):
+            raise SrtError(load_library().srt_last_error(None).decode())
+        return buf.raw
+
+    def comm_init(self, unique_id, rank, world):
+        self._check(self.lib.srt_comm_init(self._h, C.c_char_p(unique_id), rank, world))
+
+    def gather(self, root=0):
+        """ONE ncclGather of the packed canvases to `root` + unpermute there (asynchronous, collective)."""
+        self._check(self.lib.srt_gather(self._h, root))
+
+    def resolve_gathered(self, ticks_stopped):
+        self._check(self.lib.srt_resolve_gathered(self._h, ticks_stopped))
+
+    def gathered_buffers(self):
+        cp, ap = C.c_void_p(), C.c_void_p()
+        self._check(self.lib.srt_gathered_buffers(self._h, C.byref(cp), C.byref(ap)))
+        return cp.value, ap.value
+
+    def read_gathered(self, canvas=True, argb=False):
+        c = np.zeros((self.height, self.width, 4), np.float32) if canvas else None
+        a = np.zeros((self.height, self.width, 4), np.uint8) if argb else None
+        self._check(self.lib.srt_read_gathered(self._h, _ptr(c) if canvas else None, _ptr(a) if argb else None))
+        return c, a
+
+    # -- frame pipeline --
+    def render_pipelined(self, ticks_stopped, output):
+        """Enqueue this frame, receive the previous one in `output`; returns its index or -1."""
+        assert output.dtype == np.uint8 and output.size >= self.owned_rows * self.width * 4
+        rd = R.as_records(self.options, R.RENDER_DATA)
+        n = C.c_longlong(-1)
+        self._check(self.lib.srt_render_pipelined(self._h, _ptr(rd), ticks_stopped, _ptr(output), C.byref(n)))
+        return n.value
+
+    def pipeline_flush(self, output):
+        n = C.c_longlong(-1)
+        self._check(self.lib.srt_pipeline_flush(self._h, _ptr(output), C.byref(n)))
+        return n.value
+
     def set_partition(self, rank, world, rows_per_block=8):
         self._check(self.lib.srt_set_partition(self._h, rank, world, rows_per_block))
         self.owned_rows = self.lib.srt_partition_owned_rows(self.height, rank, world, rows_per_block)
+
+
+class TracerGroup:
+    """One process driving several GPUs (srt_group_*): the reference's Tracer interface over a row partition,
+    collected with one ncclGather per frame."""
+
+    def __init__(self, width, height, n_devices=1, devices=None, rows_per_block=8):
+        self.lib = load_library()
+        self._g = C.c_void_p()
+        devs = (C.c_int * n_devices)(*devices) if devices is not None else None
+        rc = self.lib.srt_group_create(width, height, n_devices, devs, rows_per_block, C.byref(self._g))
+        if rc:
+            raise SrtError(self.lib.srt_last_error(None).decode())
+        self.width, self.height, self.n_devices = width, height, n_devices
+        self.options = R.render_data(width, height, num_samples=4, num_bounces=10)
+        self.scene_data = R.scene_data(0)
+
+    def _check(self, rc):
+        if rc:
+            raise SrtError(self.lib.srt_group_last_error(self._g).decode())
+
+    def close(self):
+        if getattr(self, "_g", None) is not None and self._g.value:
+            self.lib.srt_group_destroy(self._g)
+            self._g = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_skybox(self, rgba):
+        rgba = np.ascontiguousarray(rgba, np.float32)
+        self._check(self.lib.srt_group_set_skybox(self._g, _ptr(rgba), rgba.shape[1], rgba.shape[0]))
+
+    def set_acceleration(self, mode):
+        self._check(self.lib.srt_group_set_acceleration(self._g, int(mode)))
+
+    def update_scene(self, shapes, triangles, materials):
+        shapes = R.as_records(shapes, R.SHAPE)
+        triangles = R.as_records(triangles, R.TRIANGLE)
+        materials = R.as_records(materials, R.MATERIAL)
+        sd = R.as_records(self.scene_data, R.SCENE_DATA)
+        self._check(self.lib.srt_group_update_scene(self._g, _ptr(shapes), len(shapes), _ptr(triangles), len(triangles), _ptr(materials),
+                                                    len(materials), _ptr(sd)))
+        self.scene_data["num_shapes"] = len(shapes)
+
+    def clear_canvas(self):
+        self._check(self.lib.srt_group_clear_canvas(self._g))
+
+    def render(self, ticks_stopped, output=None):
+        if output is None:
+            output = np.zeros(self.height * self.width * 4, np.uint8)
+        rd = R.as_records(self.options, R.RENDER_DATA)
+        self._check(self.lib.srt_group_render(self._g, _ptr(rd), ticks_stopped, _ptr(output)))
+        return output
+
+    def read_canvas(self):
+        out = np.zeros((self.height, self.width, 4), np.float32)
+        self._check(self.lib.srt_group_read_canvas(self._g, _ptr(out)))
+        return out
+
+    def counters(self):
+        c = Counters()
+        self._check(self.lib.srt_group_get_counters(self._g, C.byref(c)))
+        return c.as_dict()
 
 
 # ---- pure-host partition helpers (no GPU) ------------------------------------------

@@ -1,0 +1,138 @@
+"""GPU (MI355X): what happens to a frame after the trace kernel beyond one blocking device (csrc/srt_collect.hip):
+the in-library RCCL gather (one process per GPU: srt_comm_* / srt_gather; one process, several GPUs: srt_group_*)
+and the two-deep frame pipeline. One GPU is what the test box has, so the collective runs with world = 1 -- the
+communicator, the ncclGather call, the unpermute kernel and the resolve of the gathered image are the real ones; the
+N > 1 layout is covered bit for bit by the virtual-tile and gloo tests (test_gpu_parity.py, test_partition_gloo.py)
+and by the unpermute check below, which feeds the kernel a hand-packed 3-rank buffer."""
+import numpy as np
+import pytest
+
+import golden_io
+from conftest import bits_equal
+
+pytestmark = pytest.mark.gpu
+CASES = golden_io.load_cases()
+
+
+@pytest.fixture(scope="module")
+def T():
+    from simple_raytracer_amd import build, tracer
+    build.build_hip()
+    return tracer
+
+
+def test_group_of_one_device_renders_the_golden_frames(T, sky):
+    """srt_group_*: the reference's call sequence through a device group (here: one device), every frame through
+    ncclCommInitAll's communicator and ncclGather."""
+    for name in ("mixed", "spheres_accum"):
+        g = CASES[name]
+        h, w = g["argb"].shape[:2]
+        grp = T.TracerGroup(w, h, 1, rows_per_block=8)
+        grp.set_skybox(sky)
+        grp.options = g["rd"].copy()
+        grp.scene_data = g["sd"].copy()
+        grp.update_scene(g["shapes"], g["tris"], g["mats"])
+        grp.clear_canvas()
+        out = None
+        for i, tm in enumerate(g["frames"]):
+            grp.options["time"] = np.uint32(tm)
+            out = grp.render(i + 1)
+        assert bits_equal(grp.read_canvas(), g["canvas"]), name
+        assert np.array_equal(out.reshape(g["argb"].shape), g["argb"]), name
+        c = grp.counters()
+        assert c["paths"] == w * h * int(g["rd"]["num_samples"]) * len(g["frames"]) and c["watchdog"] == 0
+        grp.close()
+
+
+def test_comm_gather_world_of_one_equals_direct_read(T, sky):
+    """srt_comm_unique_id / srt_comm_init / srt_gather / srt_resolve_gathered on a world of one rank."""
+    g = CASES["glass"]
+    h, w = g["argb"].shape[:2]
+    t = T.Tracer(w, h)
+    t.set_skybox(sky)
+    t.options, t.scene_data = g["rd"].copy(), g["sd"].copy()
+    t.update_scene(g["shapes"], g["tris"], g["mats"])
+    t.set_partition(0, 1, 8)
+    with pytest.raises(T.SrtError):
+        t.gather(0)  # no communicator yet
+    t.comm_init(T.Tracer.comm_unique_id(), 0, 1)
+    t.clear_canvas()
+    t.trace()
+    t.gather(0)
+    t.resolve_gathered(1)
+    canvas, argb = t.read_gathered(canvas=True, argb=True)
+    assert bits_equal(canvas, g["canvas"]) and np.array_equal(argb, g["argb"])
+    t.close()
+
+
+def test_pipelined_frames_equal_blocking_frames(T, sky):
+    """srt_render_pipelined hands out frame N-1 while frame N is in flight: every delivered frame's bytes equal the
+    blocking srt_render sequence, in order, and the flush delivers the last one."""
+    g = CASES["spheres"]
+    h, w = g["argb"].shape[:2]
+    times = [12345, 777, 31337, 4242, 99]
+
+    def tracer():
+        t = T.Tracer(w, h)
+        t.set_skybox(sky)
+        t.options, t.scene_data = g["rd"].copy(), g["sd"].copy()
+        t.update_scene(g["shapes"], g["tris"], g["mats"])
+        t.clear_canvas()
+        return t
+
+    t = tracer()
+    want = []
+    for i, tm in enumerate(times):
+        t.options["time"] = np.uint32(tm)
+        want.append(t.render(i + 1).copy())
+    want_canvas = t.read_canvas()
+    t.close()
+
+    t = tracer()
+    got = {}
+    buf = np.zeros(w * h * 4, np.uint8)
+    for i, tm in enumerate(times):
+        t.options["time"] = np.uint32(tm)
+        n = t.render_pipelined(i + 1, buf)
+        assert n == i - 1
+        if n >= 0:
+            got[n] = buf.copy()
+    n = t.pipeline_flush(buf)
+    assert n == len(times) - 1
+    got[n] = buf.copy()
+    assert t.pipeline_flush(buf) == -1  # nothing left in flight
+    for i in range(len(times)):
+        assert np.array_equal(got[i], want[i]), f"frame {i}"
+    assert bits_equal(t.read_canvas(), want_canvas)
+    t.close()
+
+
+def test_unpermute_kernel_on_a_hand_packed_three_rank_buffer(T, sky):
+    """The root's unpermute kernel against srt_partition_unpermute (host) on a world of 3: the test packs what three
+    ranks would send and binds it as the gathered buffer through a world-3 group emulation on one handle."""
+    import ctypes as C
+    import torch
+    lib = T.load_library()
+    w, h, world, rpb = 40, 37, 3, 4
+    padded = T.padded_rows(h, world, rpb)
+    rng = np.random.RandomState(5)
+    image = rng.rand(h, w, 4).astype(np.float32)
+    packed = np.zeros((world, padded, w, 4), np.float32)
+    for r in range(world):
+        for lr in range(padded):
+            y = T.global_row(h, r, world, rpb, lr)
+            if y >= 0:
+                packed[r, lr] = image[y]
+    assert np.array_equal(T.unpermute(packed.reshape(world * padded, w, 4), h, world, rpb), image)  # the host helper
+    # the device kernel is exercised through a rank-0-of-1 handle whose canvas IS the packed buffer of a virtual world:
+    # world = 1 keeps RCCL real, rows_per_block = padded rows * world makes the layout trivial -> covered above;
+    # here the layout itself: gather three virtual ranks by rendering nothing and copying `packed` in, via torch
+    dev = torch.device("cuda", 0)
+    src = torch.from_numpy(packed).to(dev)
+    out = torch.zeros((h, w, 4), dtype=torch.float32, device=dev)
+    if not hasattr(lib, "srt_unpermute_device"):
+        pytest.skip("library built without the test hook")
+    lib.srt_unpermute_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]
+    assert lib.srt_unpermute_device(C.c_void_p(src.data_ptr()), C.c_void_p(out.data_ptr()), w, h, world, rpb) == 0
+    torch.cuda.synchronize()
+    assert np.array_equal(out.cpu().numpy(), image)

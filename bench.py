@@ -198,6 +198,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--accel", default="none", choices=["none", "bvh"],
                     help="bvh = opt-in acceleration structure for model shapes (srt_set_acceleration); the headline line uses none")
+    ap.add_argument("--gather", default="lib", choices=["lib", "torch"],
+                    help="N > 1: lib = the library's own ncclGather + unpermute kernel (srt_gather, C ABI); torch = torch.distributed.gather + index_select")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo = REHEARSAL ONLY on a box with fewer GPUs than ranks: ranks share cuda:0 and the gather is staged through host memory")
     args = ap.parse_args()
@@ -217,7 +219,10 @@ def main():
         local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    # SRT_BENCH_COLLECT=1 under a one-rank torchrun walks the N > 1 path (process group, RCCL id broadcast, srt_gather,
+    # gathered == single check) with world = 1: the rehearsal a one-GPU box allows for the RCCL leg
+    collect = world > 1 or (bool(os.environ.get("SRT_BENCH_COLLECT")) and "WORLD_SIZE" in os.environ)
+    if collect:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if rehearsal:
             dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -248,15 +253,31 @@ def main():
     t.set_partition(rank, world, args.rows_per_block)
     t.bind_canvas(canvas_t.data_ptr(), canvas_t.numel() * 4)
     argb_t = torch.zeros((h, w, 4), dtype=torch.uint8, device=dev) if rank == 0 else None
-    unperm = torch.as_tensor(multi.unpermute_index(h, world, args.rows_per_block, part.padded), device=dev) if (rank == 0 and world > 1) else None
-    gather_bufs = [torch.empty_like(canvas_t) for _ in range(world)] if (rank == 0 and world > 1) else None
+    unperm = torch.as_tensor(multi.unpermute_index(h, world, args.rows_per_block, part.padded), device=dev) if (rank == 0 and collect) else None
+    gather_bufs = [torch.empty_like(canvas_t) for _ in range(world)] if (rank == 0 and collect) else None
+
+    # the library's own collective (srt_comm_init / srt_gather): rank 0 makes the RCCL id, torch.distributed ships it
+    gather_mode = "none" if not collect else ("host-staged gloo (rehearsal)" if rehearsal else "torch.distributed.gather")
+    if collect and not rehearsal and args.gather == "lib":
+        try:
+            ids = [T.Tracer.comm_unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(ids, src=0)
+            t.comm_init(ids[0], rank, world)
+            gather_mode = "srt_gather (ncclGather inside libsrt_hip.so)"
+        except Exception as e:  # keep the run alive on the torch path, and say so in the line
+            gather_mode = f"torch.distributed.gather (srt_comm_init failed: {e})"
+        flags = [gather_mode.startswith("srt_gather")]
+        dist.all_gather_object(allf := [None] * world, flags[0])
+        if not all(allf):
+            gather_mode = "torch.distributed.gather (srt_comm_init failed on some rank)"
+    use_lib_gather = gather_mode.startswith("srt_gather")
 
     trace_ms, resolve_ms, kernel_only_ms = [], [], []
 
     def step(record):
         t.clear_canvas()
         t.trace()
-        if world > 1:
+        if collect:
             if rehearsal:
                 host = canvas_t.cpu()
                 bufs = [torch.empty_like(host) for _ in range(world)] if rank == 0 else None
@@ -264,9 +285,13 @@ def main():
                 if rank == 0:
                     for dst_buf, src in zip(gather_bufs, bufs):
                         dst_buf.copy_(src)
+            elif use_lib_gather:
+                t.gather(0)  # the ONE collective of the path: ncclGather over xGMI + unpermute kernel on rank 0, inside the library
+                if rank == 0:
+                    t.resolve_gathered(1)
             else:
-                dist.gather(canvas_t, gather_bufs, dst=0)  # the ONE collective of the path (RCCL over xGMI)
-            if rank == 0:
+                dist.gather(canvas_t, gather_bufs, dst=0)  # the same collective through torch
+            if rank == 0 and not use_lib_gather:
                 full = torch.cat(gather_bufs, dim=0).index_select(0, unperm)
                 t.resolve_external(full.data_ptr(), w * h, 1, argb_t.data_ptr())
                 step.full = full
@@ -280,7 +305,7 @@ def main():
 
     def fence():
         torch.cuda.synchronize(dev)
-        if world > 1:
+        if collect:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
@@ -301,14 +326,14 @@ def main():
     red_dev = torch.device("cpu") if rehearsal else dev
     stats = torch.tensor([elapsed, float(np.mean(kernel_only_ms)) if kernel_only_ms else 0.0], dtype=torch.float64, device=red_dev)
     cnt = torch.tensor([c["rays"], c["paths"], c["sky"], c["nan_pixels"]], dtype=torch.int64, device=red_dev)
-    if world > 1:
+    if collect:
         dist.all_reduce(stats, op=dist.ReduceOp.MAX)
         dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
     elapsed_max, trace_ms_max = float(stats[0]), float(stats[1])
     rays, paths, nsky, nan_px = (int(v) for v in cnt.tolist())
 
     check = None
-    if rank == 0 and world > 1 and os.environ.get("SRT_BENCH_CHECK", "1") != "0":
+    if rank == 0 and collect and os.environ.get("SRT_BENCH_CHECK", "1") != "0":
         # outside the timed region: the gathered, unpermuted canvas must equal a single-handle render of the whole frame bit for bit
         ref_t = T.Tracer(w, h, device=local_rank)
         ref_t.set_skybox(sky)
@@ -317,7 +342,7 @@ def main():
         ref_t.clear_canvas()
         ref_t.trace()
         want = ref_t.read_canvas()
-        got = step.full.cpu().numpy()
+        got = t.read_gathered(canvas=True)[0] if use_lib_gather else step.full.cpu().numpy()
         check = same_bits(want, got)
         ref_t.close()
     if rank == 0:
@@ -359,7 +384,7 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": desc + (f" [spp overridden to {spp}]" if args.spp else ""), "width": w, "height": h, "spp": spp,
-                       "bounces": nb, "shapes": int(len(shapes)), "triangles": int(len(tris)), "partition": f"{world} x interleaved {args.rows_per_block}-row blocks" if world > 1 else "single GPU",
+                       "bounces": nb, "shapes": int(len(shapes)), "triangles": int(len(tris)), "partition": f"{world} x interleaved {args.rows_per_block}-row blocks" if world > 1 else "single GPU", "gather": gather_mode,
                        "mode": "parity (fp-contract off, IEEE div/sqrt; canvas bit-identical to the CPU oracle)",
                        **({"accel": {"kind": "bvh", **t.acceleration_info(), "note": "triangle counters are the BVH walk's leaf tests; node box tests are not in W_ops"}} if args.accel == "bvh" else {})},
             "mpath_per_s": round(paths / elapsed_max / 1e6, 2),
@@ -397,7 +422,7 @@ def main():
             t.close()
             raise SystemExit("bench.py: the timed canvas differs from its checker (see gpu_equals_port / gathered_equals_single_gpu in the line above)")
     t.close()
-    if world > 1:
+    if collect:
         dist.destroy_process_group()
 
 

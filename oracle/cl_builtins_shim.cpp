@@ -39,6 +39,50 @@ static thread_local size_t g_gid[3];
 size_t get_global_id(uint d) { return d < 3 ? g_gid[d] : 0; }
 
 // ---- built-ins (C++ overloads mangle to the names the object imports) ---------
+#ifdef SHIM_LIBM
+// Second opinion (-DSHIM_LIBM -> oracle/_ref/libsrt_ref_libm.so): the same reference object with the built-ins
+// a textbook implementation would supply -- glibc's cosf / logf / powf / atan2f, unfused dot / cross / mix,
+// normalize = v / sqrt(dot(v, v)) with IEEE division. Not bit-comparable with anything (a path tracer is chaotic);
+// tests/test_oracle_statistics.py checks that renders with detmath's built-ins agree with it STATISTICALLY
+// (mean and RMSE at raised sample counts): detmath's choices are unbiased, not just within ULP bounds.
+#include <cmath>
+float dot(float3 a, float3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
+float3 cross(float3 a, float3 b) {
+	float3 r;
+	r.x = a.y * b.z - a.z * b.y;
+	r.y = a.z * b.x - a.x * b.z;
+	r.z = a.x * b.y - a.y * b.x;
+	return r;
+}
+float sqrt(float x) { return sqrtf(x); }
+float3 sqrt(float3 v) {
+	float3 r;
+	r.x = sqrtf(v.x);
+	r.y = sqrtf(v.y);
+	r.z = sqrtf(v.z);
+	return r;
+}
+float3 normalize(float3 v) {
+	float len = sqrtf(dot(v, v));
+	float3 r;
+	r.x = v.x / len;
+	r.y = v.y / len;
+	r.z = v.z / len;
+	return r;
+}
+float3 mix(float3 x, float3 y, float a) {
+	float3 r;
+	r.x = x.x + (y.x - x.x) * a;
+	r.y = x.y + (y.y - x.y) * a;
+	r.z = x.z + (y.z - x.z) * a;
+	return r;
+}
+float pow(float x, float y) { return powf(x, y); }
+double pown(double x, int n) { return std::pow(x, (double)n); }
+float atan2pi(float y, float x) { return (float)(std::atan2((double)y, (double)x) / 3.14159265358979323846); }
+float cos(float x) { return cosf(x); }
+float log(float x) { return logf(x); }
+#else
 float dot(float3 a, float3 b) { return dm_dot3(a.x, a.y, a.z, b.x, b.y, b.z); }
 float3 cross(float3 a, float3 b) {
 	float3 r;
@@ -71,6 +115,12 @@ float3 mix(float3 x, float3 y, float a) {
 	r.z = dm_mix(x.z, y.z, a);
 	return r;
 }
+float pow(float x, float y) { return dm_powf(x, y); }
+double pown(double x, int n) { return dm_pown_d(x, n); }
+float atan2pi(float y, float x) { return dm_atan2pif(y, x); }
+float cos(float x) { return dm_cosf(x); }
+float log(float x) { return dm_logf(x); }
+#endif
 float3 clamp(float3 v, float3 lo, float3 hi) {
 	float3 r;
 	r.x = dm_clamp(v.x, lo.x, hi.x);
@@ -82,11 +132,6 @@ float fabs(float x) { return dm_fabs(x); }
 float min(float x, float y) { return dm_min(x, y); }
 float max(float x, float y) { return dm_max(x, y); }
 float sign(float x) { return dm_sign(x); }
-float pow(float x, float y) { return dm_powf(x, y); }
-double pown(double x, int n) { return dm_pown_d(x, n); }
-float atan2pi(float y, float x) { return dm_atan2pif(y, x); }
-float cos(float x) { return dm_cosf(x); }
-float log(float x) { return dm_logf(x); }
 
 // ---- image sampling: OpenCL 3.0 §8.2, CLK_NORMALIZED_COORDS_TRUE |
 // CLK_ADDRESS_CLAMP_TO_EDGE | CLK_FILTER_LINEAR (reference src/tracer.cpp:47-48) ----

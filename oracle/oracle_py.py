@@ -28,6 +28,10 @@ def ref_available():
     return (HERE / "_ref" / "libsrt_ref.so").exists()
 
 
+def ref_libm_available():
+    return (HERE / "_ref" / "libsrt_ref_libm.so").exists()
+
+
 def _p(a):
     return a.ctypes.data_as(C.c_void_p)
 
@@ -56,6 +60,8 @@ class Oracle:
                 build()
         elif kind == "ref":
             path, self.px = HERE / "_ref" / "libsrt_ref.so", "ref_"
+        elif kind == "ref_libm":  # the reference object with glibc behind cos / log / pow / atan2 (statistics only)
+            path, self.px = HERE / "_ref" / "libsrt_ref_libm.so", "ref_"
         else:
             raise ValueError(kind)
         self.lib = C.CDLL(str(path))

@@ -85,14 +85,54 @@ def test_obj_variants_and_errors(headless, tmp_path):
     assert subprocess.run([headless, "--scene", "empty", "--obj", str(bad), "--parse-only"], capture_output=True).returncode == 3
 
 
+def hand_written_stl(path):
+    """A binary STL assembled byte by byte here (not by scenes.write_stl), as the format the reference reads
+    (src/parser.cpp:24-50): 80 header bytes, u32 count, then 50-byte records {normal, v1, v2, v3, u16 attribute}."""
+    import struct
+    facets = [  # a tetrahedron; facet normals as an exporter would write them (not unit length on purpose for one)
+        ((0.0, 0.0, -1.0), (0, 0, 0), (0, 1, 0), (1, 0, 0)),
+        ((0.0, -2.0, 0.0), (0, 0, 0), (1, 0, 0), (0, 0, 1)),
+        ((-1.0, 0.0, 0.0), (0, 0, 0), (0, 0, 1), (0, 1, 0)),
+        ((0.57735026, 0.57735026, 0.57735026), (1, 0, 0), (0, 1, 0), (0, 0, 1)),
+    ]
+    blob = b"solid written by hand for tests/test_host_mirror.py".ljust(80, b" ") + struct.pack("<I", len(facets))
+    for k, (n, a, b, c) in enumerate(facets):
+        blob += struct.pack("<12fH", *n, *a, *b, *c, 0xBEEF + k)  # attribute bytes must be skipped, whatever they hold
+    assert len(blob) == 84 + 50 * len(facets)
+    path.write_bytes(blob)
+    return facets
+
+
+def test_stl_loader_on_hand_written_bytes(headless, tmp_path):
+    stl = tmp_path / "tetra.stl"
+    facets = hand_written_stl(stl)
+    prefix = str(tmp_path / "t")
+    subprocess.run([headless, "--scene", "empty", "--stl", str(stl), "--parse-only", "--dump", prefix], check=True)
+    shapes, tris, _ = _load(prefix)
+    t = tris[12:]
+    assert len(t) == len(facets)
+    for got, (n, a, b, c) in zip(t, facets):
+        assert np.array_equal(got["v"]["pos"], np.array([a, b, c], np.float32))
+        assert np.array_equal(got["v"]["normal"], np.tile(np.array(n, np.float32), (3, 1)))  # facet normal on all three vertices, verbatim
+    m = shapes[shapes["type"] == 2][-1]
+    assert int(m["triangle_index"]) == 12 and int(m["num_triangles"]) == 4
+    # a file cut short mid-record yields its complete records, not 4 triangles with garbage in them (host/parser.hpp:15;
+    # the reference would push whatever its stack buffer held, src/parser.cpp:42-47)
+    (tmp_path / "cut.stl").write_bytes(stl.read_bytes()[:84 + 50 * 2 + 7])
+    subprocess.run([headless, "--scene", "empty", "--stl", str(tmp_path / "cut.stl"), "--parse-only", "--dump", prefix], check=True)
+    _, tris, _ = _load(prefix)
+    assert len(tris) == 12 + 2 and np.array_equal(tris[12:]["v"]["pos"], t[:2]["v"]["pos"])
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("extra", [[], ["--bvh"]], ids=["array_scan", "bvh"])
 def test_cxx_tracer_renders_like_oracle_and_writes_ppm(extra, headless, tmp_path, oracle, sky):
-    obj = tmp_path / "m.obj"
+    obj, stl = tmp_path / "m.obj", tmp_path / "tetra.stl"
     S.write_obj(obj, S.blob_mesh(10, 11, seed=3, smooth=True))
+    hand_written_stl(stl)  # an STL-loaded, flat-shaded model next to the OBJ one
     prefix, ppm = str(tmp_path / "r"), tmp_path / "frame.ppm"
     w, h, spp, frames = 96, 64, 3, 2
-    subprocess.run([headless, "--scene", "meshes", "--obj", str(obj), "--width", str(w), "--height", str(h), "--spp", str(spp),
+    subprocess.run([headless, "--scene", "meshes", "--obj", str(obj), "--stl", str(stl), "--width", str(w), "--height", str(h), "--spp", str(spp),
                     "--frames", str(frames), "--time", "4242", "--out", str(ppm), "--dump", prefix] + extra, check=True)
     shapes, tris, mats = _load(prefix)
     rd = np.fromfile(prefix + ".rd.bin", R.RENDER_DATA)[0]

@@ -26,7 +26,7 @@ struct ShapeRun { /* host side only: a block while it is being packed */
 	uint32_t data_off;
 };
 struct BlockGroup {
-	uint32_t code;     /* byte k = block k of the group: (shape type + 1) | shapes in the block << 2; 0 = no block */
+	uint32_t code;     /* byte k = block k of the group: (shape type + 1) | shapes in the block << 2 | big model << 5; 0 = no block */
 	uint32_t first[3]; /* index of each block's first shape */
 };
 static_assert(sizeof(BlockGroup) == 16, "BlockGroup 16 B");
@@ -146,6 +146,7 @@ void srt_launch_trace(TraceParams p, bool count_triangles, int num_waves, void *
 void srt_launch_reduce(const ReduceParams &p, void *stream);
 int srt_trace_waves_per_simd(int has_models, int use_bvh);
 int srt_trace_resident_waves_per_cu(const TraceParams &p, bool count_triangles); /* from the runtime's occupancy calculator */
+int srt_scan_suspend_min(void); /* array scan: models of at least this many triangles sit alone in their block and are flagged big */
 int srt_sub_job_items(int has_models, int use_bvh); /* items per LDS-staged sub-job; chunks per atomic are multiples of it */
 void srt_launch_prepass(const PrepassParams &p, uint64_t total_wtris, void *stream);
 void srt_launch_resolve(const ResolveParams &p, void *stream);

@@ -556,7 +556,7 @@ __device__ __forceinline__ f3 sky_box(const TraceParams &p, f3 dir) {
 #define SRT_SUB_PLAIN 64
 #endif
 #ifndef SRT_SUB_MODELS
-#define SRT_SUB_MODELS 128
+#define SRT_SUB_MODELS 64
 #endif
 #ifndef SRT_SUB_BVH
 #define SRT_SUB_BVH 128
@@ -568,6 +568,15 @@ __device__ __forceinline__ f3 sky_box(const TraceParams &p, f3 dir) {
 // paths the hit queue holds; when hits + queued paths exceed it they are shaded even if they do not fill the wave
 #ifndef SRT_HQ_CAP
 #define SRT_HQ_CAP 48
+#endif
+// Array-scan kernels: a model of at least this many triangles ("big", srt_abi.hip packs it alone in its block) is not
+// scanned by the few lanes whose rays happen to enter its box in one EXTEND phase; those rays wait in the scan
+// queue until a wave-full of them has gathered (unless at least SRT_SCAN_NOW_MIN lanes want the scan anyway).
+#ifndef SRT_SCAN_SUSPEND_MIN
+#define SRT_SCAN_SUSPEND_MIN 128
+#endif
+#ifndef SRT_SCAN_NOW_MIN
+#define SRT_SCAN_NOW_MIN 48
 #endif
 // new camera rays are only set up when at least this many lanes are free
 #ifndef SRT_REFILL_MIN
@@ -715,6 +724,11 @@ __global__ __launch_bounds__(64, USE_BVH ? SRT_TRACE_WAVES_PER_SIMD_BVH : HAS_MO
 	float *__restrict__ ring = stage + 2u * SUB * 3u;                          // [10][64] escaped paths awaiting their sky lookup
 	float *__restrict__ hq = ring + 10u * 64u;                                 // [16..18][HQ] paths that hit, awaiting their bounce (FIFO)
 	constexpr uint32_t HQ = SRT_HQ_CAP;
+	// array-scan kernels: rays waiting for the triangle scan of a big model (stack of 64 records x 19 fields)
+	constexpr bool SUSPEND = HAS_MODELS && !USE_BVH;
+	constexpr uint32_t SQ = 64u;
+	float *__restrict__ sq = hq + (HAS_MODELS ? (USE_BVH ? 18u : 17u) : 16u) * HQ;
+	uint32_t sq_count = 0; // wave-uniform
 	uint32_t ring_count = 0, hq_head = 0, hq_count = 0;                        // wave-uniform
 
 	f3 org = mk(0.f, 0.f, 0.f), dir = mk(0.f, 0.f, 0.f), mask = mk(1.f, 1.f, 1.f), color = mk(0.f, 0.f, 0.f);
@@ -725,29 +739,40 @@ __global__ __launch_bounds__(64, USE_BVH ? SRT_TRACE_WAVES_PER_SIMD_BVH : HAS_MO
 	uint32_t best_tri = 0; // index inside the model; with a BVH: absolute triangle record
 	uint32_t best_j = 0;   // BVH only: index inside the model
 	bool active = false;   // the lane holds a ray that awaits closest_intersection
+	float tmin = DM_INF_F; // closest hit so far of the ray under way (kept across a suspension)
+	uint32_t pos = 0;      // SUSPEND: first shape block this ray still has to see (0 = a fresh ray)
+	bool resumed = false;  // SUSPEND: the ray was taken back from the scan queue and scans the model of block `pos` now
 	// rays / sky / paths are counted per WAVE with popcounts of the exec mask (scalar adds, no
 	// VGPRs); only the instrumented triangle counters stay per lane.
 	// (paths and sky lookups of a wave stay below the launch's 2^32 items; iterations are diagnostics)
 	unsigned long long w_rays = 0;
 	uint32_t w_sky = 0, w_paths = 0, w_orphans = 0, w_evict = 0, w_iter = 0, w_shade = 0;
+	uint32_t w_scans = 0, w_scan_lanes = 0; // SUSPEND diagnostics, per lane: triangle scans of big models this lane led / took part in
 	uint32_t n_tri = 0, n_tri_u = 0;
 	uint32_t idle_spins = 0;
 
 	SRT_CLK_DECL;
 	for (;;) {
 		bool hit = false, missed = false, fin = false;
+		bool suspended = false; // SUSPEND: the lane's ray went to the scan queue in this iteration
 		w_iter++;
 		SRT_CLK(6);
 		// ================= EXTEND: closest_intersection (render.cl:293-378), winner deferred =================
 		if (__any(active)) {
-			if (nb > 0) w_rays += (unsigned long long)__popcll(__ballot(active));
+			if (nb > 0) w_rays += (unsigned long long)__popcll(__ballot(active && !(SUSPEND && resumed))); // a resumed ray was counted when it set out
 			if (active) {
 				if (nb <= 0) { // render.cl:403: no bounce loop at all -> colour 0
 					fin = true;
 				} else {
-					float tmin = DM_INF_F;
-					best = -1;
-					best_tri = 0, best_j = 0;
+					if (!SUSPEND || !resumed) {
+						tmin = DM_INF_F;
+						best = -1;
+						best_tri = 0, best_j = 0;
+						pos = 0;
+					}
+					bool part = true;       // SUSPEND: false once the ray has gone to the scan queue
+					uint32_t sq_pushed = 0; // records pushed by this EXTEND phase so far. Uniform among the lanes in here only:
+					                        // sq_count itself, which the lanes outside this branch read too, is brought up to date after it
 					f3 inv = mk(0.f, 0.f, 0.f);
 					if (HAS_MODELS) inv = mk(1.0f / dir.x, 1.0f / dir.y, 1.0f / dir.z);
 
@@ -758,15 +783,50 @@ __global__ __launch_bounds__(64, USE_BVH ? SRT_TRACE_WAVES_PER_SIMD_BVH : HAS_MO
 					// the three blocks of a group are fetched with four scalar loads issued together: one scalar-memory
 					// round trip per group (a 7-shape scene is one group). The mesh kernels, whose triangle loops need
 					// the scalar registers, fetch the blocks of a group one by one instead.
-					auto test_block = [&](const Blk16 &b, uint32_t code, int base) {
+					auto test_block = [&](const Blk16 &b, uint32_t code, int base, uint32_t bidx) {
 						const uint32_t type1 = code & 3u; // shape type + 1; 0 = no block
+						const bool on = !SUSPEND || (part && bidx >= pos);
 						if (type1 == SRT_SHAPE_SPHERE + 1u) {
-							test_spheres4(b, org, dir, base, tmin, best);
+							if (on) test_spheres4(b, org, dir, base, tmin, best);
 						} else if (type1 == SRT_SHAPE_PLANE + 1u) {
-							test_planes2(b, org, dir, base, tmin, best);
+							if (on) test_planes2(b, org, dir, base, tmin, best);
 						} else if (HAS_MODELS && type1 == SRT_SHAPE_MODEL + 1u) {
 							// the model's own box first, exactly as the reference (render.cl:316-323), then its triangles
-							if (test_aabb(b.v[0], b.v[1], b.v[2], b.v[4], b.v[5], b.v[6], org, inv, tmin)) {
+							const bool enter0 = on && test_aabb(b.v[0], b.v[1], b.v[2], b.v[4], b.v[5], b.v[6], org, inv, tmin);
+							bool scan0 = enter0;
+							if (SUSPEND && ((code >> 5) & 1u)) {
+								// A big model. Few of a wave's rays enter its box at a time; scanning 10^5 triangles for them would
+								// leave the other lanes idle. Those rays wait in the scan queue -- with everything closest_intersection
+								// has found so far, so that they continue exactly where they left -- until a wave-full has gathered.
+								const unsigned long long want = __ballot(enter0);
+								const uint32_t n_want = (uint32_t)__popcll(want);
+								const bool now = queue_dry || n_want >= (uint32_t)SRT_SCAN_NOW_MIN || sq_count + sq_pushed + n_want > SQ || __any(enter0 && resumed);
+								if (!now) {
+									if (enter0) {
+										const uint32_t e = sq_count + sq_pushed + __builtin_amdgcn_mbcnt_hi((uint32_t)(want >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)want, 0u));
+										sq[0 * SQ + e] = org.x, sq[1 * SQ + e] = org.y, sq[2 * SQ + e] = org.z;
+										sq[3 * SQ + e] = dir.x, sq[4 * SQ + e] = dir.y, sq[5 * SQ + e] = dir.z;
+										sq[6 * SQ + e] = mask.x, sq[7 * SQ + e] = mask.y, sq[8 * SQ + e] = mask.z;
+										sq[9 * SQ + e] = color.x, sq[10 * SQ + e] = color.y, sq[11 * SQ + e] = color.z;
+										sq[12 * SQ + e] = dm_u2f(seed), sq[13 * SQ + e] = dm_u2f((uint32_t)bounce), sq[14 * SQ + e] = dm_u2f(item);
+										sq[15 * SQ + e] = tmin, sq[16 * SQ + e] = dm_u2f((uint32_t)best), sq[17 * SQ + e] = dm_u2f(best_tri);
+										sq[18 * SQ + e] = dm_u2f(bidx);
+										part = false;
+										suspended = true;
+									}
+									sq_pushed += n_want;
+									scan0 = false;
+								}
+							}
+							if (SUSPEND && !COUNT_TRIS && ((code >> 5) & 1u)) {
+								// per LANE (this is divergent code): summed over the wave at the end
+								const unsigned long long sb = __ballot(scan0);
+								if (scan0) {
+									w_scan_lanes++;
+									if ((sb & ((1ull << lane) - 1ull)) == 0ull) w_scans++; // the scan's first lane counts the scan
+								}
+							}
+							if (scan0) {
 								if (USE_BVH) {
 									if (f2u(b.v[7]) != 0u)
 										walk_bvh<COUNT_TRIS>(p.bvh_nodes, p.bvh_tris, f2u(b.v[3]), org, dir, base, tmin, best, best_tri, best_j, n_tri, n_tri_u);
@@ -775,7 +835,7 @@ __global__ __launch_bounds__(64, USE_BVH ? SRT_TRACE_WAVES_PER_SIMD_BVH : HAS_MO
 									test_triangles<COUNT_TRIS>(wtris, f2u(b.v[3]), f2u(b.v[7]), org, dir, base, tmin, best, best_tri, n_tri_u);
 								}
 							}
-							if ((code >> 2) > 1u && test_aabb(b.v[8], b.v[9], b.v[10], b.v[12], b.v[13], b.v[14], org, inv, tmin)) {
+							if (((code >> 2) & 7u) > 1u && on && test_aabb(b.v[8], b.v[9], b.v[10], b.v[12], b.v[13], b.v[14], org, inv, tmin)) {
 								if (USE_BVH) {
 									if (f2u(b.v[15]) != 0u)
 										walk_bvh<COUNT_TRIS>(p.bvh_nodes, p.bvh_tris, f2u(b.v[11]), org, dir, base + 1, tmin, best, best_tri, best_j, n_tri, n_tri_u);
@@ -794,26 +854,30 @@ __global__ __launch_bounds__(64, USE_BVH ? SRT_TRACE_WAVES_PER_SIMD_BVH : HAS_MO
 						const float *__restrict__ gd = run_data + 48 * g;
 						if (!HAS_MODELS) {
 							const Blk16 b0 = ld_blk16(gd), b1 = ld_blk16(gd + 16), b2 = ld_blk16(gd + 32);
-							test_block(b0, code & 255u, (int)f2u(gh[1]));
-							test_block(b1, (code >> 8) & 255u, (int)f2u(gh[2]));
-							test_block(b2, (code >> 16) & 255u, (int)f2u(gh[3]));
+							test_block(b0, code & 255u, (int)f2u(gh[1]), 0u);
+							test_block(b1, (code >> 8) & 255u, (int)f2u(gh[2]), 0u);
+							test_block(b2, (code >> 16) & 255u, (int)f2u(gh[3]), 0u);
 						} else {
-							test_block(ld_blk16(gd), code & 255u, (int)f2u(gh[1]));
-							if ((code >> 8) & 255u) test_block(ld_blk16(gd + 16), (code >> 8) & 255u, (int)f2u(gh[2]));
-							if ((code >> 16) & 255u) test_block(ld_blk16(gd + 32), (code >> 16) & 255u, (int)f2u(gh[3]));
+							test_block(ld_blk16(gd), code & 255u, (int)f2u(gh[1]), 3u * g);
+							if ((code >> 8) & 255u) test_block(ld_blk16(gd + 16), (code >> 8) & 255u, (int)f2u(gh[2]), 3u * g + 1u);
+							if ((code >> 16) & 255u) test_block(ld_blk16(gd + 32), (code >> 16) & 255u, (int)f2u(gh[3]), 3u * g + 2u);
 						}
 					}
+					if (SUSPEND) resumed = false;
 					// a shape without a material counts as a miss (render.cl:404: material_index >= 0)
-					int material_index = -1;
-					if (best >= 0) material_index = USE_LDS ? (int)f2u(reinterpret_cast<const float *>(lds)[8 * best + 1]) : p.winners[best].material;
-					hit = material_index >= 0;
-					missed = !hit;
-					if (hit) org = org + dir * tmin; // rayhit->position (render.cl:312,343,362)
+					if (!SUSPEND || part) { // else: the ray waits in the scan queue, with all of its state
+						int material_index = -1;
+						if (best >= 0) material_index = USE_LDS ? (int)f2u(reinterpret_cast<const float *>(lds)[8 * best + 1]) : p.winners[best].material;
+						hit = material_index >= 0;
+						missed = !hit;
+						if (hit) org = org + dir * tmin; // rayhit->position (render.cl:312,343,362)
+					}
 				}
 				active = false;
 			}
 		}
 
+		if (SUSPEND) sq_count += (uint32_t)__popcll(__ballot(suspended)); // wave-uniform again
 		SRT_CLK(0);
 		// ---- escaped paths queue for the sky (wave-uniform control flow) ----
 		const unsigned long long mm = __ballot(missed);
@@ -1014,8 +1078,31 @@ __global__ __launch_bounds__(64, USE_BVH ? SRT_TRACE_WAVES_PER_SIMD_BVH : HAS_MO
 
 		SRT_CLK(4);
 		// ================= REFILL: free lanes take new camera rays =================
-		const unsigned long long freeb = __ballot(!active);
-		const uint32_t n_free = (uint32_t)__popcll(freeb);
+		unsigned long long freeb = __ballot(!active);
+		uint32_t n_free = (uint32_t)__popcll(freeb);
+		if (SUSPEND && sq_count != 0u && n_free != 0u &&
+		    (queue_dry || (n_free >= (uint32_t)SRT_REFILL_MIN && sq_count >= (n_free < (uint32_t)SRT_SCAN_NOW_MIN ? n_free : (uint32_t)SRT_SCAN_NOW_MIN)))) {
+			// rays that wait for a big model's triangle scan come first: together they fill the wave for it
+			asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+			const uint32_t n_pop = n_free < sq_count ? n_free : sq_count;
+			const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(freeb >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)freeb, 0u));
+			if (!active && rank < n_pop) {
+				const uint32_t e = sq_count - 1u - rank;
+				org = mk(sq[0 * SQ + e], sq[1 * SQ + e], sq[2 * SQ + e]);
+				dir = mk(sq[3 * SQ + e], sq[4 * SQ + e], sq[5 * SQ + e]);
+				mask = mk(sq[6 * SQ + e], sq[7 * SQ + e], sq[8 * SQ + e]);
+				color = mk(sq[9 * SQ + e], sq[10 * SQ + e], sq[11 * SQ + e]);
+				seed = dm_f2u(sq[12 * SQ + e]), bounce = (int)dm_f2u(sq[13 * SQ + e]), item = dm_f2u(sq[14 * SQ + e]);
+				tmin = sq[15 * SQ + e], best = (int)dm_f2u(sq[16 * SQ + e]), best_tri = dm_f2u(sq[17 * SQ + e]);
+				pos = dm_f2u(sq[18 * SQ + e]);
+				resumed = true;
+				active = true;
+			}
+			asm volatile("" ::: "memory");
+			sq_count -= n_pop;
+			freeb = __ballot(!active);
+			n_free = (uint32_t)__popcll(freeb);
+		}
 		if (!queue_dry && n_free >= (uint32_t)SRT_REFILL_MIN) {
 			const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(freeb >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)freeb, 0u));
 			uint32_t given = 0; // free lanes served so far (wave-uniform)
@@ -1103,7 +1190,7 @@ __global__ __launch_bounds__(64, USE_BVH ? SRT_TRACE_WAVES_PER_SIMD_BVH : HAS_MO
 		}
 
 		SRT_CLK(5);
-		if (!__any(active) && hq_count == 0u) {
+		if (!__any(active) && hq_count == 0u && sq_count == 0u) {
 			if (queue_dry) break;
 			// Bounded: a wave that spins here without ever getting work leaves with the watchdog counter set instead of hanging.
 			if (++idle_spins > (1u << 20)) {
@@ -1120,8 +1207,8 @@ __global__ __launch_bounds__(64, USE_BVH ? SRT_TRACE_WAVES_PER_SIMD_BVH : HAS_MO
 	if (st.total1 != 0u) flush_stage(stage + SUB * 3u, p.radiance + 3ull * st.base1, st.total1, lane);
 
 	// per-wave counters: this wave's own 64-byte line, no atomics (device_types.h)
-	unsigned long long t3 = n_tri, t4 = n_tri_u;
-	if (COUNT_TRIS) {
+	unsigned long long t3 = COUNT_TRIS ? n_tri : w_scans, t4 = COUNT_TRIS ? n_tri_u : w_scan_lanes;
+	if (COUNT_TRIS || SUSPEND) {
 		for (int off = 32; off > 0; off >>= 1) {
 			t3 += __shfl_down(t3, off);
 			t4 += __shfl_down(t4, off);
@@ -1135,6 +1222,9 @@ __global__ __launch_bounds__(64, USE_BVH ? SRT_TRACE_WAVES_PER_SIMD_BVH : HAS_MO
 		if (COUNT_TRIS) {
 			w[3] += t3;
 			w[4] += t4;
+		} else if (SUSPEND) { // diagnostics in the slots the instrumented variant uses for triangle counts
+			w[8] += t3;
+			w[9] += t4;
 		}
 		w[5] += (unsigned long long)w_orphans + ((unsigned long long)w_evict << 40); // diagnostics (srt_debug_counters)
 		w[6] += w_iter;
@@ -1355,12 +1445,13 @@ void srt_launch_selftest(unsigned long long *out, uint32_t stride, void *stream)
 int srt_trace_waves_per_simd(int has_models, int use_bvh) {
 	return !has_models ? SRT_TRACE_WAVES_PER_SIMD : use_bvh ? SRT_TRACE_WAVES_PER_SIMD_BVH : SRT_TRACE_WAVES_PER_SIMD_MODELS;
 }
+int srt_scan_suspend_min(void) { return SRT_SCAN_SUSPEND_MIN; }
 int srt_sub_job_items(int has_models, int use_bvh) { return !has_models ? SRT_SUB_PLAIN : use_bvh ? SRT_SUB_BVH : SRT_SUB_MODELS; }
 
 int srt_trace_lds_floats(int has_models, int use_bvh) {
 	// two staging buffers of packed 12-byte items, the sky ring (10 fields), the hit queue (16..18 fields)
 	const int sub = srt_sub_job_items(has_models, use_bvh);
-	return 2 * sub * 3 + 10 * 64 + (has_models ? (use_bvh ? 18 : 17) : 16) * SRT_HQ_CAP;
+	return 2 * sub * 3 + 10 * 64 + (has_models ? (use_bvh ? 18 : 17) : 16) * SRT_HQ_CAP + (has_models && !use_bvh ? 19 * 64 : 0);
 }
 
 namespace {

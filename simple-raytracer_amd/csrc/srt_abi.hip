@@ -496,13 +496,16 @@ static int update_scene_impl(srt_tracer *t, const srt_shape *shapes, size_t n_sh
 		}
 		if (s.type != SRT_SHAPE_SPHERE && s.type != SRT_SHAPE_PLANE && s.type != SRT_SHAPE_MODEL) continue; // ignored, as render.cl:301-366
 		const uint32_t block_cap = s.type == SRT_SHAPE_SPHERE ? 4u : 2u;
-		if (runs.empty() || runs.back().type != s.type || runs.back().first_shape + runs.back().count != i || runs.back().count == block_cap) {
+		// array scan: a big model sits alone in its block (data_off's top bit marks the block until the headers are built)
+		const bool big_model = !use_bvh && s.type == SRT_SHAPE_MODEL && s.shape.model.num_triangles >= (uint32_t)srt_scan_suspend_min();
+		const bool prev_big = !runs.empty() && (runs.back().data_off >> 31);
+		if (runs.empty() || runs.back().type != s.type || runs.back().first_shape + runs.back().count != i || runs.back().count == block_cap || big_model || prev_big) {
 			pad_run();
 			ShapeRun r;
 			r.type = s.type;
 			r.first_shape = (uint32_t)i;
 			r.count = 0;
-			r.data_off = (uint32_t)data.size(); // = 16 * block number
+			r.data_off = (uint32_t)data.size() | (big_model ? 0x80000000u : 0u); // = 16 * block number
 			runs.push_back(r);
 		}
 		runs.back().count++;
@@ -601,7 +604,7 @@ static int update_scene_impl(srt_tracer *t, const srt_shape *shapes, size_t n_sh
 	for (size_t b = 0; b < runs.size(); b++) {
 		BlockGroup &g = groups[b / 3];
 		if (b % 3 == 0) memset(&g, 0, sizeof g);
-		g.code |= (((uint32_t)runs[b].type + 1u) | (runs[b].count << 2)) << (8 * (b % 3));
+		g.code |= (((uint32_t)runs[b].type + 1u) | (runs[b].count << 2) | ((runs[b].data_off >> 31) << 5)) << (8 * (b % 3));
 		g.first[b % 3] = runs[b].first_shape;
 	}
 	data.resize(groups.size() * 48 + 16, 0.0f);
@@ -680,6 +683,7 @@ static int update_scene_impl(srt_tracer *t, const srt_shape *shapes, size_t n_sh
 	t->sd = *scene;
 	t->sd.num_shapes = (int32_t)n_shapes; // src/tracer.cpp:94
 	t->num_models = num_models;
+	t->scan_tris = use_bvh ? 0 : total_wtris;
 	t->bvh_active = use_bvh && num_models > 0;
 	t->bvh_info[0] = bvh_nodes.size(), t->bvh_info[1] = bvh_leaves, t->bvh_info[2] = bvh_depth, t->bvh_info[3] = use_bvh ? build_us : 0;
 	t->bvh_info[4] = use_bvh ? plan.size() - bvh_reused - bvh_refitted : 0, t->bvh_info[5] = bvh_reused, t->bvh_info[6] = bvh_refitted;
@@ -767,6 +771,15 @@ int srt_trace(srt_tracer *t, const srt_render_data *options) {
 		const size_t fit32 = (size_t)0xfffffff0u / pixels;
 		if (fit32 < fit) fit = fit32 ? fit32 : 1;
 		if (fit < batch) batch = (uint32_t)fit;
+		// Array scan of large meshes: a ray that enters a model's box tests every triangle, so one launch over all samples
+		// can run for tens of seconds (BASELINE configs[4]: ~14 s) -- longer than a compute queue should be held. Sample
+		// batches bound a launch by 2e12 ray-triangle pairs if EVERY path entered every box (a few seconds at worst).
+		if (t->scan_tris > 4096) {
+			const double per_sample = (double)pixels * (double)t->scan_tris;
+			const double cap = 2e12 / per_sample;
+			const uint32_t cap_u = cap < 1.0 ? 1u : (cap > 1e9 ? 0xffffffffu : (uint32_t)cap);
+			if (cap_u < batch) batch = cap_u;
+		}
 		if (batch > 4 && (batch & 3u)) batch &= ~3u; // keep the reduce kernel's 16-byte loads aligned
 	}
 	// allocate; if the device cannot give that much right now, fall back to smaller batches

@@ -75,6 +75,7 @@ struct srt_tracer {
 	int sky_w = 0, sky_h = 0;
 	srt_scene_data sd{};
 	int num_models = 0;
+	uint64_t scan_tris = 0; // array scan: triangles of the models a ray can be made to scan (all of them), for the launch-length bound
 	bool scene_set = false;
 	bool count_tris = false;
 	int rank = 0, world = 1, rows_per_block = 8, owned_rows = 0;

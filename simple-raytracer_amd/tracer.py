@@ -261,7 +261,9 @@ class Tracer:
         v = [int(x) for x in out]
         return {"rays": v[0], "sky": v[1], "paths": v[2], "orphans": v[5] & ((1 << 40) - 1), "evictions": v[5] >> 40,
                 "iterations": v[6], "shade_phases": v[7], "waves_per_cu": v[8], "grid": v[9],
-                "phase_cycles": dict(zip(("extend", "ring", "shade", "park", "deliver", "refill", "head", "kernel"), v[10:18]))}
+                "phase_cycles": dict(zip(("extend", "ring", "shade", "park", "deliver", "refill", "head", "kernel"), v[10:18])),
+                # array-scan kernels without -DSRT_PHASE_CLOCK reuse the first two clock slots: big-model scans and the lanes in them
+                "scans": v[10], "scan_lanes": v[11]}
 
     def reset_counters(self):
         self._check(self.lib.srt_reset_counters(self._h))

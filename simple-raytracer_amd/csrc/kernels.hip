@@ -445,7 +445,7 @@ __device__ __forceinline__ void test_triangles(const float *__restrict__ wtris, 
 //  * the scan keeps the FIRST triangle of equal t (strict <, render.cl:254-256): a hit with
 //    t == tmin inside the same model replaces the incumbent only if its index j is lower.
 template <bool COUNT_TRIS>
-__device__ __forceinline__ void walk_bvh(const BvhNode *__restrict__ nodes, const float *__restrict__ recs, uint32_t root, f3 org, f3 dir, int idx,
+__device__ __forceinline__ void walk_bvh(const BvhNode *__restrict__ nodes, const float *__restrict__ recs, uint32_t root0, uint32_t nodes_per_octant, f3 org, f3 dir, int idx,
                                          float &tmin, int &best, uint32_t &best_rec, uint32_t &best_j, uint32_t &n_tri, uint32_t &n_tri_u) {
 	// 1/d, or +-2^100 where |d| < 2^-100: (lo - o) * inv stays finite (no 0 * inf = NaN), and keeps its sign
 	f3 inv;
@@ -454,7 +454,9 @@ __device__ __forceinline__ void walk_bvh(const BvhNode *__restrict__ nodes, cons
 	inv.z = dm_fabs(dir.z) >= 0x1p-100f ? 1.0f / dir.z : __builtin_copysignf(0x1p100f, dir.z);
 	const float4 *__restrict__ n4 = reinterpret_cast<const float4 *>(nodes);
 	const float4 *__restrict__ r4 = reinterpret_cast<const float4 *>(recs);
-	uint32_t node = root;
+	// the copy of the hierarchy that is ordered front to back for this ray's sign pattern (srt_abi.hip emit_octant)
+	const uint32_t oct = (f2u(dir.x) >> 31) | ((f2u(dir.y) >> 31) << 1) | ((f2u(dir.z) >> 31) << 2);
+	uint32_t node = root0 + oct * nodes_per_octant;
 	while (node != SRT_BVH_END) {
 		const float4 a = n4[2u * node], b = n4[2u * node + 1u];
 		const float x1 = (a.x - org.x) * inv.x, x2 = (b.x - org.x) * inv.x;
@@ -559,7 +561,7 @@ __device__ __forceinline__ f3 sky_box(const TraceParams &p, f3 dir) {
 #define SRT_SUB_MODELS 64
 #endif
 #ifndef SRT_SUB_BVH
-#define SRT_SUB_BVH 128
+#define SRT_SUB_BVH 64
 #endif
 // SHADE runs when hits + queued paths reach this many lanes (64 = always a full wave)
 #ifndef SRT_SHADE_MIN
@@ -577,6 +579,9 @@ __device__ __forceinline__ f3 sky_box(const TraceParams &p, f3 dir) {
 #endif
 #ifndef SRT_SCAN_NOW_MIN
 #define SRT_SCAN_NOW_MIN 48
+#endif
+#ifndef SRT_HQ_CAP_BVH
+#define SRT_HQ_CAP_BVH SRT_HQ_CAP
 #endif
 // new camera rays are only set up when at least this many lanes are free
 #ifndef SRT_REFILL_MIN
@@ -723,7 +728,7 @@ __global__ __launch_bounds__(64, USE_BVH ? SRT_TRACE_WAVES_PER_SIMD_BVH : HAS_MO
 	float *__restrict__ stage = reinterpret_cast<float *>(lds + p.stage_off); // [2][SUB] packed {r, g, b}
 	float *__restrict__ ring = stage + 2u * SUB * 3u;                          // [10][64] escaped paths awaiting their sky lookup
 	float *__restrict__ hq = ring + 10u * 64u;                                 // [16..18][HQ] paths that hit, awaiting their bounce (FIFO)
-	constexpr uint32_t HQ = SRT_HQ_CAP;
+	constexpr uint32_t HQ = USE_BVH ? SRT_HQ_CAP_BVH : SRT_HQ_CAP;
 	// array-scan kernels: rays waiting for the triangle scan of a big model (stack of 64 records x 19 fields)
 	constexpr bool SUSPEND = HAS_MODELS && !USE_BVH;
 	constexpr uint32_t SQ = 64u;
@@ -829,7 +834,7 @@ __global__ __launch_bounds__(64, USE_BVH ? SRT_TRACE_WAVES_PER_SIMD_BVH : HAS_MO
 							if (scan0) {
 								if (USE_BVH) {
 									if (f2u(b.v[7]) != 0u)
-										walk_bvh<COUNT_TRIS>(p.bvh_nodes, p.bvh_tris, f2u(b.v[3]), org, dir, base, tmin, best, best_tri, best_j, n_tri, n_tri_u);
+										walk_bvh<COUNT_TRIS>(p.bvh_nodes, p.bvh_tris, f2u(b.v[3]), f2u(b.v[7]), org, dir, base, tmin, best, best_tri, best_j, n_tri, n_tri_u);
 								} else {
 									if (COUNT_TRIS) n_tri += f2u(b.v[7]);
 									test_triangles<COUNT_TRIS>(wtris, f2u(b.v[3]), f2u(b.v[7]), org, dir, base, tmin, best, best_tri, n_tri_u);
@@ -838,7 +843,7 @@ __global__ __launch_bounds__(64, USE_BVH ? SRT_TRACE_WAVES_PER_SIMD_BVH : HAS_MO
 							if (((code >> 2) & 7u) > 1u && on && test_aabb(b.v[8], b.v[9], b.v[10], b.v[12], b.v[13], b.v[14], org, inv, tmin)) {
 								if (USE_BVH) {
 									if (f2u(b.v[15]) != 0u)
-										walk_bvh<COUNT_TRIS>(p.bvh_nodes, p.bvh_tris, f2u(b.v[11]), org, dir, base + 1, tmin, best, best_tri, best_j, n_tri, n_tri_u);
+										walk_bvh<COUNT_TRIS>(p.bvh_nodes, p.bvh_tris, f2u(b.v[11]), f2u(b.v[15]), org, dir, base + 1, tmin, best, best_tri, best_j, n_tri, n_tri_u);
 								} else {
 									if (COUNT_TRIS) n_tri += f2u(b.v[15]);
 									test_triangles<COUNT_TRIS>(wtris, f2u(b.v[11]), f2u(b.v[15]), org, dir, base + 1, tmin, best, best_tri, n_tri_u);
@@ -1451,7 +1456,7 @@ int srt_sub_job_items(int has_models, int use_bvh) { return !has_models ? SRT_SU
 int srt_trace_lds_floats(int has_models, int use_bvh) {
 	// two staging buffers of packed 12-byte items, the sky ring (10 fields), the hit queue (16..18 fields)
 	const int sub = srt_sub_job_items(has_models, use_bvh);
-	return 2 * sub * 3 + 10 * 64 + (has_models ? (use_bvh ? 18 : 17) : 16) * SRT_HQ_CAP + (has_models && !use_bvh ? 19 * 64 : 0);
+	return 2 * sub * 3 + 10 * 64 + (has_models ? (use_bvh ? 18 * SRT_HQ_CAP_BVH : 17 * SRT_HQ_CAP) : 16 * SRT_HQ_CAP) + (has_models && !use_bvh ? 19 * 64 : 0);
 }
 
 namespace {

@@ -210,6 +210,62 @@ struct BvhBuilder {
 		}
 	}
 
+	// One octant's copy of a hierarchy. `c` is the canonical form build() leaves: depth-first, the left child (lower
+	// centroids along the split axis) directly behind its parent, the right child at the left one's skip link; indices
+	// relative to the model. The copy is appended to `out` (absolute links) in the depth-first order in which a ray whose
+	// direction has the sign pattern `oct` (bit a set = negative along axis a) meets the NEARER child of each pair first:
+	// the two children are compared along the axis on which their box centres differ most.
+	static void emit_octant(const std::vector<BvhNode> &c, int oct, uint32_t rec_off, std::vector<BvhNode> &out) {
+		if (c.empty()) return;
+		const size_t start = out.size();
+		struct Frame {
+			uint32_t ci;   // canonical node
+			uint32_t self; // its copy in out; ~0u = not emitted yet
+			uint32_t second;
+			int stage;
+		};
+		std::vector<Frame> stack;
+		stack.push_back({0u, ~0u, 0u, 0});
+		while (!stack.empty()) {
+			Frame &f = stack.back();
+			if (f.stage == 0) {
+				f.self = (uint32_t)out.size();
+				out.push_back(c[f.ci]);
+				if (c[f.ci].leaf) {
+					out[f.self].leaf = c[f.ci].leaf + rec_off;
+					out[f.self].skip = (uint32_t)out.size();
+					stack.pop_back();
+					continue;
+				}
+				const uint32_t left = f.ci + 1u, right = c[left].skip;
+				int axis = 0;
+				float best = -1.0f, delta = 0.0f;
+				for (int a = 0; a < 3; a++) {
+					const float d = (0.5f * c[right].lo[a] + 0.5f * c[right].hi[a]) - (0.5f * c[left].lo[a] + 0.5f * c[left].hi[a]);
+					if (std::isfinite(d) && std::fabs(d) > best) best = std::fabs(d), axis = a, delta = d;
+				}
+				const bool negative_dir = (oct >> axis) & 1;
+				const bool left_first = (delta >= 0.0f) != negative_dir; // right lies further along +axis: nearer for a ray going the negative way
+				f.second = left_first ? right : left;
+				f.stage = 1;
+				const uint32_t first = left_first ? left : right;
+				stack.push_back({first, ~0u, 0u, 0}); // invalidates f
+				continue;
+			}
+			if (f.stage == 1) {
+				f.stage = 2;
+				const uint32_t second = f.second;
+				stack.push_back({second, ~0u, 0u, 0});
+				continue;
+			}
+			out[f.self].skip = (uint32_t)out.size();
+			stack.pop_back();
+		}
+		const uint32_t end = (uint32_t)out.size();
+		for (size_t i = start; i < out.size(); i++)
+			if (out[i].skip == end) out[i].skip = SRT_BVH_END;
+	}
+
 	// Appends the model's nodes and triangle order; returns the root's index.
 	uint32_t run(const srt_model &m, const srt_triangle *all, uint32_t first_record) {
 		rec_base = first_record;
@@ -460,7 +516,7 @@ static int update_scene_impl(srt_tracer *t, const srt_shape *shapes, size_t n_sh
 	const bool use_bvh = t->accel_mode == SRT_ACCEL_BVH;
 	std::vector<BvhNode> bvh_nodes;
 	std::vector<uint32_t> bvh_order;
-	uint64_t bvh_leaves = 0, bvh_depth = 0, bvh_reused = 0, bvh_refitted = 0;
+	uint64_t bvh_leaves = 0, bvh_depth = 0, bvh_reused = 0, bvh_refitted = 0, bvh_canonical_nodes = 0;
 	std::deque<BvhCacheEntry> fresh;                 // hierarchies built by this call (deque: growth keeps references valid)
 	std::vector<std::pair<bool, size_t>> plan;       // per model with triangles: {from the cache?, index there / in fresh}
 	std::vector<std::pair<uint64_t, uint64_t>> range_hashes; // {triangle_index << 32 | count, hash}
@@ -528,6 +584,7 @@ static int update_scene_impl(srt_tracer *t, const srt_shape *shapes, size_t n_sh
 			if (total_wtris + m.num_triangles > (use_bvh ? 0x0fffffffull : 0xffffffffull))
 				return fail(t, SRT_ERR_INVALID, "srt_update_scene: too many world triangles");
 			uint32_t link = (uint32_t)total_wtris; // brute force: first world triangle of the model
+			uint32_t bvh_npo = 0;                  // BVH: nodes per octant copy (0 = a model without triangles: nothing to walk)
 			if (use_bvh && m.num_triangles > 0) {
 				// hash of this triangle range, once per distinct range per call (instances share ranges)
 				uint64_t th = 0;
@@ -576,20 +633,22 @@ static int update_scene_impl(srt_tracer *t, const srt_shape *shapes, size_t n_sh
 					ent->leaves = bb.leaves, ent->depth = bb.max_depth;
 					plan.emplace_back(false, fresh.size() - 1);
 				}
-				// indices inside an entry are relative to its first node / first record
+				// Indices inside an entry are relative to its first node / first record. The device gets the hierarchy
+				// EIGHT times, once per sign pattern of a ray's direction: the same nodes, in the depth-first order in
+				// which that pattern meets the nearer child of every pair first (emit_octant). A lane walks the copy of
+				// its ray's octant, so its closest hit tends to come early and the skip links jump over what lies behind.
 				const uint32_t n0 = (uint32_t)bvh_nodes.size(), r0 = (uint32_t)total_wtris;
-				for (BvhNode nd : ent->nodes) {
-					if (nd.skip != SRT_BVH_END) nd.skip += n0;
-					if (nd.leaf) nd.leaf += r0; // the record index lives in the low 28 bits and r0 + records < 2^28 (checked above)
-					bvh_nodes.push_back(nd);
-				}
+				if ((uint64_t)n0 + 8ull * ent->nodes.size() >= 0xffffffffull) return fail(t, SRT_ERR_INVALID, "srt_update_scene: too many BVH nodes");
+				for (int oct = 0; oct < 8; oct++) BvhBuilder::emit_octant(ent->nodes, oct, r0, bvh_nodes); // r0 + records < 2^28 (checked above)
+				bvh_canonical_nodes += ent->nodes.size();
 				bvh_order.insert(bvh_order.end(), ent->order.begin(), ent->order.end());
-				link = n0; // BVH: its root node
+				link = n0;                              // BVH: the root of octant 0's copy ...
+				bvh_npo = (uint32_t)ent->nodes.size();  // ... and the distance to the next octant's
 				bvh_leaves += ent->leaves;
 				if (ent->depth > bvh_depth) bvh_depth = ent->depth;
 			}
 			data.insert(data.end(), {m.bounding_min.x, m.bounding_min.y, m.bounding_min.z, u2f(link), m.bounding_max.x, m.bounding_max.y,
-			                         m.bounding_max.z, u2f(m.num_triangles)});
+			                         m.bounding_max.z, u2f(use_bvh ? bvh_npo : m.num_triangles)});
 			wr.first_wtri = (uint32_t)total_wtris;
 			offs[i] = (uint32_t)total_wtris;
 			// brute force: blocks of 4, the tail stays all-zero (never hit); BVH: records are addressed one by one
@@ -685,7 +744,7 @@ static int update_scene_impl(srt_tracer *t, const srt_shape *shapes, size_t n_sh
 	t->num_models = num_models;
 	t->scan_tris = use_bvh ? 0 : total_wtris;
 	t->bvh_active = use_bvh && num_models > 0;
-	t->bvh_info[0] = bvh_nodes.size(), t->bvh_info[1] = bvh_leaves, t->bvh_info[2] = bvh_depth, t->bvh_info[3] = use_bvh ? build_us : 0;
+	t->bvh_info[0] = bvh_canonical_nodes, t->bvh_info[1] = bvh_leaves, t->bvh_info[2] = bvh_depth, t->bvh_info[3] = use_bvh ? build_us : 0;
 	t->bvh_info[4] = use_bvh ? plan.size() - bvh_reused - bvh_refitted : 0, t->bvh_info[5] = bvh_reused, t->bvh_info[6] = bvh_refitted;
 	if (use_bvh) {
 		std::vector<BvhCacheEntry> next_cache;

@@ -639,6 +639,7 @@ static int update_scene_impl(srt_tracer *t, const srt_shape *shapes, size_t n_sh
 				// its ray's octant, so its closest hit tends to come early and the skip links jump over what lies behind.
 				const uint32_t n0 = (uint32_t)bvh_nodes.size(), r0 = (uint32_t)total_wtris;
 				if ((uint64_t)n0 + 8ull * ent->nodes.size() >= 0xffffffffull) return fail(t, SRT_ERR_INVALID, "srt_update_scene: too many BVH nodes");
+				bvh_nodes.reserve(bvh_nodes.size() + 8 * ent->nodes.size());
 				for (int oct = 0; oct < 8; oct++) BvhBuilder::emit_octant(ent->nodes, oct, r0, bvh_nodes); // r0 + records < 2^28 (checked above)
 				bvh_canonical_nodes += ent->nodes.size();
 				bvh_order.insert(bvh_order.end(), ent->order.begin(), ent->order.end());

@@ -569,7 +569,7 @@ __device__ __forceinline__ f3 sky_box(const TraceParams &p, f3 dir) {
 #endif
 // paths the hit queue holds; when hits + queued paths exceed it they are shaded even if they do not fill the wave
 #ifndef SRT_HQ_CAP
-#define SRT_HQ_CAP 48
+#define SRT_HQ_CAP 40
 #endif
 // Array-scan kernels: a model of at least this many triangles ("big", srt_abi.hip packs it alone in its block) is not
 // scanned by the few lanes whose rays happen to enter its box in one EXTEND phase; those rays wait in the scan
@@ -1184,7 +1184,7 @@ __global__ __launch_bounds__(64, USE_BVH ? SRT_TRACE_WAVES_PER_SIMD_BVH : HAS_MO
 				const uint32_t sample = p.first_sample + (off - dq * nbs);
 				const uint32_t lrow = q / (uint32_t)width;
 				const int px = (int)(q - lrow * (uint32_t)width);
-				const int py = global_row((int)lrow, p.rank, p.world, p.rows_per_block);
+				const int py = p.world == 1 ? (int)lrow : global_row((int)lrow, p.rank, p.world, p.rows_per_block); // (wave-uniform choice)
 				const uint32_t id = (uint32_t)px + (uint32_t)py * (uint32_t)width;
 				seed = (sample + id * (uint32_t)ns) * p.rd.time * 5304u;
 				float ndc_x = ((float)px + random_float(seed)) / p.f_width;

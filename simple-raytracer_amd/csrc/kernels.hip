@@ -710,6 +710,13 @@ __global__ __launch_bounds__(64, USE_BVH ? SRT_TRACE_WAVES_PER_SIMD_BVH : HAS_MO
 		const float4 *__restrict__ gm = reinterpret_cast<const float4 *>(p.materials);
 		for (int i = threadIdx.x; i < 2 * n_shapes; i += 64) lds[i] = gw[i];
 		for (int i = threadIdx.x; i < 4 * p.num_materials; i += 64) lds[2 * n_shapes + i] = gm[i];
+		if (!HAS_MODELS) { // sphere / plane scenes: group headers and shape blocks too (see EXTEND)
+			const float4 *__restrict__ gh4 = reinterpret_cast<const float4 *>(p.runs);
+			const float4 *__restrict__ gd4 = reinterpret_cast<const float4 *>(p.run_data);
+			float4 *__restrict__ dst = lds + 2 * n_shapes + 4 * p.num_materials;
+			for (int i = threadIdx.x; i < p.num_runs; i += 64) dst[i] = gh4[i];
+			for (int i = threadIdx.x; i < 12 * p.num_runs; i += 64) dst[p.num_runs + i] = gd4[i];
+		}
 		__syncthreads();
 	}
 
@@ -866,8 +873,32 @@ __global__ __launch_bounds__(64, USE_BVH ? SRT_TRACE_WAVES_PER_SIMD_BVH : HAS_MO
 						ld_uniform<4, 16>(reinterpret_cast<const float *>(runs + g), gh);
 						const uint32_t code = f2u(gh[0]);
 						const float *__restrict__ gd = run_data + 48 * g;
-						if (!HAS_MODELS) {
+						if (!HAS_MODELS && USE_LDS) {
+							// Small sphere / plane scenes: the blocks were staged in LDS with the winner records. All lanes read the same
+							// address (a broadcast: no bank conflicts) and get the shape data in VGPRs; measured, the scalar-cache
+							// round trip of the path below costs a wave ~750 cycles per segment, an LDS read a fraction of that.
+							const float4 *__restrict__ lgh = lds + 2 * n_shapes + 4 * p.num_materials;
+							const float4 *__restrict__ lb = lgh + n_groups + 12 * g;
+							const float4 hv = lgh[g];
+							const uint32_t lcode = (uint32_t)__builtin_amdgcn_readfirstlane((int)f2u(hv.x));
+							const int f0 = __builtin_amdgcn_readfirstlane((int)f2u(hv.y)), f1 = __builtin_amdgcn_readfirstlane((int)f2u(hv.z)),
+							          f2 = __builtin_amdgcn_readfirstlane((int)f2u(hv.w));
+							auto ld_lds = [&](int k) {
+								Blk16 b;
+								const float4 q0 = lb[4 * k], q1 = lb[4 * k + 1], q2 = lb[4 * k + 2], q3 = lb[4 * k + 3];
+								b.v[0] = q0.x, b.v[1] = q0.y, b.v[2] = q0.z, b.v[3] = q0.w, b.v[4] = q1.x, b.v[5] = q1.y, b.v[6] = q1.z, b.v[7] = q1.w;
+								b.v[8] = q2.x, b.v[9] = q2.y, b.v[10] = q2.z, b.v[11] = q2.w, b.v[12] = q3.x, b.v[13] = q3.y, b.v[14] = q3.z, b.v[15] = q3.w;
+								return b;
+							};
+							test_block(ld_lds(0), lcode & 255u, f0, 0u);
+							if ((lcode >> 8) & 255u) test_block(ld_lds(1), (lcode >> 8) & 255u, f1, 0u);
+							if ((lcode >> 16) & 255u) test_block(ld_lds(2), (lcode >> 16) & 255u, f2, 0u);
+						} else if (!HAS_MODELS) {
 							const Blk16 b0 = ld_blk16(gd), b1 = ld_blk16(gd + 16), b2 = ld_blk16(gd + 32);
+#ifdef SRT_PHASE_CLOCK_LOADS
+							asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+							SRT_CLK(3); // (diagnosis) time until the group's scalar loads have arrived, booked on the PARK slot
+#endif
 							test_block(b0, code & 255u, (int)f2u(gh[1]), 0u);
 							test_block(b1, (code >> 8) & 255u, (int)f2u(gh[2]), 0u);
 							test_block(b2, (code >> 16) & 255u, (int)f2u(gh[3]), 0u);
@@ -1478,8 +1509,9 @@ TraceKernel pick_trace_kernel(bool models, bool use_bvh, bool use_lds, bool coun
 }
 // winners + materials go to LDS when small enough not to cost occupancy
 size_t scene_lds_bytes(const TraceParams &p) {
-	const size_t scene = (size_t)p.sd.num_shapes * sizeof(WinnerRec) + (size_t)p.num_materials * sizeof(srt_material);
-	return scene <= 4608 ? scene : 0; // both record types are multiples of 16 B
+	size_t scene = (size_t)p.sd.num_shapes * sizeof(WinnerRec) + (size_t)p.num_materials * sizeof(srt_material);
+	if (p.num_models == 0) scene += (size_t)p.num_runs * (sizeof(BlockGroup) + 192); // sphere / plane scenes: group headers + shape blocks
+	return scene <= 4608 ? scene : 0; // all record types are multiples of 16 B
 }
 } // namespace
 

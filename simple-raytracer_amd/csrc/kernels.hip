@@ -583,6 +583,10 @@ __device__ __forceinline__ f3 sky_box(const TraceParams &p, f3 dir) {
 #ifndef SRT_HQ_CAP_BVH
 #define SRT_HQ_CAP_BVH SRT_HQ_CAP
 #endif
+// entries of the sky ring (<= 64): the ring is resolved when full, one entry per lane
+#ifndef SRT_RING_CAP
+#define SRT_RING_CAP 64
+#endif
 // new camera rays are only set up when at least this many lanes are free
 #ifndef SRT_REFILL_MIN
 #define SRT_REFILL_MIN 32
@@ -663,10 +667,11 @@ __device__ __forceinline__ void resolve_ring(const TraceParams &p, const float *
 	asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 	bool f0 = false, f1 = false;
 	if ((uint32_t)lane < n) {
-		const f3 d = mk(ring[0 * 64 + lane], ring[1 * 64 + lane], ring[2 * 64 + lane]);
-		f3 m = mk(ring[3 * 64 + lane], ring[4 * 64 + lane], ring[5 * 64 + lane]);
-		f3 c = mk(ring[6 * 64 + lane], ring[7 * 64 + lane], ring[8 * 64 + lane]);
-		const uint32_t item = dm_f2u(ring[9 * 64 + lane]);
+		constexpr uint32_t RC = SRT_RING_CAP;
+		const f3 d = mk(ring[0 * RC + lane], ring[1 * RC + lane], ring[2 * RC + lane]);
+		f3 m = mk(ring[3 * RC + lane], ring[4 * RC + lane], ring[5 * RC + lane]);
+		f3 c = mk(ring[6 * RC + lane], ring[7 * RC + lane], ring[8 * RC + lane]);
+		const uint32_t item = dm_f2u(ring[9 * RC + lane]);
 		m = m * sky_box(p, d);
 		c = c + m;
 		deliver<SUB>(st, stage, p.radiance, item, c, f0, f1);
@@ -743,7 +748,7 @@ __global__ __launch_bounds__(64, USE_BVH ? SRT_TRACE_WAVES_PER_SIMD_BVH : HAS_MO
 	uint32_t issued = 0, cur = 0;                        // items of buffer `cur` handed out so far
 	float *__restrict__ stage = reinterpret_cast<float *>(lds + p.stage_off); // [2][SUB] packed {r, g, b}
 	float *__restrict__ ring = stage + 2u * SUB * 3u;                          // [10][64] escaped paths awaiting their sky lookup
-	float *__restrict__ hq = ring + 10u * 64u;                                 // [16..18][HQ] paths that hit, awaiting their bounce (FIFO)
+	float *__restrict__ hq = ring + 10u * (uint32_t)SRT_RING_CAP;                                 // [16..18][HQ] paths that hit, awaiting their bounce (FIFO)
 	constexpr uint32_t HQ = USE_BVH ? SRT_HQ_CAP_BVH : SRT_HQ_CAP;
 	// array-scan kernels: rays waiting for the triangle scan of a big model (stack of 64 records x 19 fields)
 	constexpr bool SUSPEND = HAS_MODELS && !USE_BVH;
@@ -927,19 +932,30 @@ __global__ __launch_bounds__(64, USE_BVH ? SRT_TRACE_WAVES_PER_SIMD_BVH : HAS_MO
 		// ---- escaped paths queue for the sky (wave-uniform control flow) ----
 		const unsigned long long mm = __ballot(missed);
 		if (mm != 0ull) {
+			constexpr uint32_t RC = SRT_RING_CAP;
 			const uint32_t n_miss = (uint32_t)__popcll(mm);
-			if (ring_count + n_miss > 64u) {
+			const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mm, 0u));
+			uint32_t done = 0;
+			if (ring_count + n_miss > RC) { // does not fit: the sky lookups of what is queued first (ring_count lanes busy)
 				resolve_ring<SUB>(p, ring, ring_count, st, stage, lane);
 				ring_count = 0;
 			}
-			if (missed) {
-				const uint32_t e = ring_count + __builtin_amdgcn_mbcnt_hi((uint32_t)(mm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mm, 0u));
-				ring[0 * 64 + e] = dir.x, ring[1 * 64 + e] = dir.y, ring[2 * 64 + e] = dir.z;
-				ring[3 * 64 + e] = mask.x, ring[4 * 64 + e] = mask.y, ring[5 * 64 + e] = mask.z;
-				ring[6 * 64 + e] = color.x, ring[7 * 64 + e] = color.y, ring[8 * 64 + e] = color.z;
-				ring[9 * 64 + e] = dm_u2f(item);
+			while (done < n_miss) { // one round unless more lanes escaped than the ring holds (RC < 64)
+				const uint32_t take = (RC - ring_count) < (n_miss - done) ? (RC - ring_count) : (n_miss - done);
+				if (missed && rank >= done && rank < done + take) {
+					const uint32_t e = ring_count + (rank - done);
+					ring[0 * RC + e] = dir.x, ring[1 * RC + e] = dir.y, ring[2 * RC + e] = dir.z;
+					ring[3 * RC + e] = mask.x, ring[4 * RC + e] = mask.y, ring[5 * RC + e] = mask.z;
+					ring[6 * RC + e] = color.x, ring[7 * RC + e] = color.y, ring[8 * RC + e] = color.z;
+					ring[9 * RC + e] = dm_u2f(item);
+				}
+				ring_count += take;
+				done += take;
+				if (done < n_miss) {
+					resolve_ring<SUB>(p, ring, ring_count, st, stage, lane);
+					ring_count = 0;
+				}
 			}
-			ring_count += n_miss;
 			w_sky += n_miss;
 		}
 
@@ -1493,7 +1509,7 @@ int srt_sub_job_items(int has_models, int use_bvh) { return !has_models ? SRT_SU
 int srt_trace_lds_floats(int has_models, int use_bvh) {
 	// two staging buffers of packed 12-byte items, the sky ring (10 fields), the hit queue (16..18 fields)
 	const int sub = srt_sub_job_items(has_models, use_bvh);
-	return 2 * sub * 3 + 10 * 64 + (has_models ? (use_bvh ? 18 * SRT_HQ_CAP_BVH : 17 * SRT_HQ_CAP) : 16 * SRT_HQ_CAP) + (has_models && !use_bvh ? 19 * 64 : 0);
+	return 2 * sub * 3 + 10 * SRT_RING_CAP + (has_models ? (use_bvh ? 18 * SRT_HQ_CAP_BVH : 17 * SRT_HQ_CAP) : 16 * SRT_HQ_CAP) + (has_models && !use_bvh ? 19 * 64 : 0);
 }
 
 namespace {

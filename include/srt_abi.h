@@ -102,6 +102,15 @@ int srt_acceleration_info(const srt_tracer *t, uint64_t out[7]);
 int srt_bvh_build_host(const srt_shape *model, const srt_triangle *triangles, size_t n_triangles, srt_bvh_node *nodes_out,
                        size_t nodes_cap, uint32_t *order_out, size_t order_cap, size_t *n_nodes);
 
+/* Host-only: the WIDE form of that hierarchy, the one the kernel walks (layout: csrc/device_types.h; block indices
+ * relative to the model's first block). blocks_out receives at most blocks_cap blocks of 32 dwords (leaf blocks are
+ * zero here: the device writes their triangles), dest_out[r] = (leaf block << 2) | slot of record r (records as in
+ * srt_bvh_build_host's order). *root = the root reference (0xffffffff for a model without triangles), *stack_need =
+ * the most children a walk can have waiting at once (never above the kernel's stack of 64: a hierarchy that would
+ * need more is rebuilt balanced, *balanced = 1; force_balanced != 0 asks for that form directly). */
+int srt_bvh_wide_host(const srt_shape *model, const srt_triangle *triangles, size_t n_triangles, int force_balanced, uint32_t *blocks_out,
+                      size_t blocks_cap, uint32_t *dest_out, size_t dest_cap, size_t *n_blocks, uint32_t *root, uint32_t *stack_need, int *balanced);
+
 /* Tracer::clear_canvas — src/tracer.cpp:98-101. */
 int srt_clear_canvas(srt_tracer *t);
 

@@ -86,10 +86,10 @@ typedef struct srt_shape {
 	} shape;
 } srt_shape;
 
-/* One node of the optional BVH over a model's triangles (srt_set_acceleration in srt_abi.h;
- * new, no counterpart in the reference). Nodes of a model are stored in depth-first order; a
- * ray enters node + 1 when it hits an inner node's box and continues at `skip` otherwise
- * (after a leaf, too), until SRT_BVH_END: no stack. */
+/* One node of the binary hierarchy the host builds over a model's triangles (srt_set_acceleration
+ * in srt_abi.h; new, no counterpart in the reference) and srt_bvh_build_host hands out. Nodes of a
+ * model are stored in depth-first order: an inner node's first child is node + 1, its second child
+ * that child's `skip`. The device walks a four-wide folding of it (srt_bvh_wide_host). */
 typedef struct srt_bvh_node {
 	float lo[3];
 	uint32_t skip; /* first node after this node's subtree, or SRT_BVH_END */

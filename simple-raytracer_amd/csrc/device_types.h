@@ -49,19 +49,28 @@ static_assert(sizeof(WinnerRec) == 32, "WinnerRec 32 B");
 #define SRT_WTRI_FLOATS 9
 
 /* Optional acceleration structure (srt_set_acceleration, include/srt_abi.h; SURVEY.md 8(f)
- * row 4). One binary BVH per model instance over its world-space triangles, built on the
- * host at srt_update_scene. Nodes are stored in depth-first order and carry a SKIP link (the
- * node that follows their subtree), so a lane walks the tree with one index and no stack:
- *     box hit, inner -> node + 1        box hit, leaf -> test its triangles, then skip
- *     box missed     -> skip            SRT_BVH_END ends the walk
- * Indices only ever grow, so every walk ends after at most `node count` steps.
- * Triangles are re-ordered so that a leaf's triangles are consecutive 48-byte records
- * {v0, e1, e2, j, 0, 0} (j = index inside the model, for the reference's first-in-array-
- * order tie rule and for the vertex normals), values as in SRT_WTRI_FLOATS above. */
+ * row 4). Per model instance the host builds a binary SAH hierarchy over the world-space triangles
+ * (srt_bvh_node, include/srt_types.h: the form that is cached, refitted and handed out by
+ * srt_bvh_build_host) and folds it into the WIDE form the kernel walks: 128-byte blocks, one cache
+ * line and one fetch each.
+ *   inner block  dwords 0-3 lo.x of children 0..3, 4-7 hi.x, 8-11 lo.y, 12-15 hi.y, 16-19 lo.z,
+ *                20-23 hi.z, 24-27 their references, 28-31 zero
+ *   leaf block   up to three triangles of SRT_BVH_TRI_FLOATS dwords {v0, e1, e2, j} (values as in
+ *                SRT_WTRI_FLOATS above; j = index inside the model, for the reference's first-in-
+ *                array-order tie rule and for the vertex normals), written by srt_prepass_kernel;
+ *                unused slots stay zero
+ *   reference    SRT_BVH_NONE = no child; else block index (absolute, < 2^28), bit 31 = leaf,
+ *                bits 28-29 = triangles in the leaf
+ * A lane keeps the children it still has to enter on a stack of SRT_BVH_STACK_CAP entries; the host
+ * checks every hierarchy against that bound (srt_abi.hip fold_wide) and falls back to a balanced one. */
 typedef srt_bvh_node BvhNode; /* include/srt_types.h */
-#define SRT_BVH_TRI_FLOATS 12
+#define SRT_BVH_TRI_FLOATS 10
+#define SRT_BVH_NONE 0xffffffffu
+#define SRT_BVH_LEAF_BIT 0x80000000u
+#define SRT_BVH_INDEX_MASK 0x0fffffffu
+#define SRT_BVH_STACK_CAP 64
 #ifndef SRT_BVH_LEAF_MAX
-#define SRT_BVH_LEAF_MAX 2 /* A/B at full size, configs[4] / configs[2]: 1: 68.5 / 75.2 ms, 2: 69.2 / 75.6, 4: 75.7 / 80.5, 8: 90.0 / 90.1 */
+#define SRT_BVH_LEAF_MAX 3 /* triangles per leaf block */
 #endif
 
 /* Work counters are kept per persistent wave (workgroup index), one 64-byte line each, and
@@ -107,8 +116,7 @@ struct TraceParams {
 	int32_t num_models;
 	int32_t rank, world, rows_per_block, owned_rows;
 	int32_t use_bvh;          /* model records carry a BVH root instead of a first world triangle */
-	const BvhNode *bvh_nodes; /* all models' nodes; links are absolute indices */
-	const float *bvh_tris;    /* SRT_BVH_TRI_FLOATS per record, leaf order */
+	const float *bvh_blocks;  /* all models' 128-byte blocks (wide hierarchy above) */
 };
 
 struct PrepassParams {
@@ -119,6 +127,7 @@ struct PrepassParams {
 	int32_t num_shapes;
 	uint32_t num_triangles; /* size of the triangle array, for bounds clamping */
 	const uint32_t *order;  /* BVH layout: record wtri_offset[shape] + s holds triangle order[wtri_offset[shape] + s]; NULL = array order, 9 floats */
+	const uint32_t *dest;   /* BVH layout: (leaf block << 2) | slot of that record inside `wtris` (= the block array) */
 };
 
 /* Ordered reduction of a batch: per pixel, colour += radiance[pixel][k] for k in order

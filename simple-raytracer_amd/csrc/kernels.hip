@@ -434,56 +434,119 @@ __device__ __forceinline__ void test_triangles(const float *__restrict__ wtris, 
 	}
 }
 
-// ---- BVH walk (opt-in; device_types.h BvhNode) -------------------------------------------
-// Per lane: rays of a wave are incoherent after the first bounce, so nodes and triangles come
-// through per-lane loads (the tree of a 10^5-triangle model is ~5 MB: L2 / Infinity Cache
-// resident). Same Moller-Trumbore as the brute-force loop, so every accepted hit has the same
-// t; what the walk must guarantee is that the triangle the array-order scan would settle on
-// is visited and wins:
-//  * boxes were padded on the host and the slab test below errs towards "hit" (safe inverse
-//    for zero direction components, relative slack on the exit distance);
+// ---- BVH walk (opt-in; device_types.h "wide hierarchy") ------------------------------------
+// Per lane: rays of a wave are incoherent after the first bounce, so blocks come through per-lane
+// loads, and a walk is a chain of dependent fetches whose latency nothing else in the wave covers
+// (profiles/README.md: the binary, own-box, skip-linked form spent 64 % of its wave cycles in
+// s_waitcnt, VALU 12 % busy). Hence 128-byte blocks that one fetch (8 x 16 B in flight) brings in
+// whole: an inner block holds the boxes of FOUR children, a leaf block up to three triangles, so a
+// ray takes about a quarter of the dependent steps of a binary walk, and the hierarchy of a 10^5-
+// triangle model is 8.5 MB instead of the 21 MB of eight octant-ordered copies. Children are visited
+// nearest first by their entry distance; the others wait, with that distance, on a per-lane stack in
+// scratch memory whose top entry lives in registers (a pop never waits for memory unless the entry it
+// uncovers is culled as well).
+// Same Moller-Trumbore as the array scan, so every accepted hit has the same t; what the walk must
+// guarantee is that the triangle the array-order scan would settle on is visited and wins:
+//  * boxes were padded on the host and the slab test errs towards "hit" (safe inverse for zero
+//    direction components, relative slack on the exit distance and on the stacked entry distance);
 //  * the scan keeps the FIRST triangle of equal t (strict <, render.cl:254-256): a hit with
 //    t == tmin inside the same model replaces the incumbent only if its index j is lower.
+struct BvhStackEntry {
+	uint32_t ref;
+	float t;
+};
+
+__device__ __forceinline__ void bvh_child(float lox, float hix, float loy, float hiy, float loz, float hiz, uint32_t ref, f3 org, f3 inv, float tmin,
+                                          float &t_out, uint32_t &ref_out) {
+	const float x1 = (lox - org.x) * inv.x, x2 = (hix - org.x) * inv.x;
+	const float y1 = (loy - org.y) * inv.y, y2 = (hiy - org.y) * inv.y;
+	const float z1 = (loz - org.z) * inv.z, z2 = (hiz - org.z) * inv.z;
+	const float tn = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(x1, x2), __builtin_fminf(y1, y2)), __builtin_fmaxf(__builtin_fminf(z1, z2), 0.0f));
+	const float tf = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(x1, x2), __builtin_fmaxf(y1, y2)), __builtin_fminf(__builtin_fmaxf(z1, z2), tmin));
+	const bool hit = tn <= tf * 1.000001f && ref != SRT_BVH_NONE;
+	t_out = hit ? tn : __builtin_inff();
+	ref_out = hit ? ref : SRT_BVH_NONE;
+}
+
+__device__ __forceinline__ void bvh_order2(float &ta, uint32_t &ra, float &tb, uint32_t &rb) {
+	const bool swap = tb < ta;
+	const float t0 = swap ? tb : ta, t1 = swap ? ta : tb;
+	const uint32_t r0 = swap ? rb : ra, r1 = swap ? ra : rb;
+	ta = t0, tb = t1, ra = r0, rb = r1;
+}
+
 template <bool COUNT_TRIS>
-__device__ __forceinline__ void walk_bvh(const BvhNode *__restrict__ nodes, const float *__restrict__ recs, uint32_t root0, uint32_t nodes_per_octant, f3 org, f3 dir, int idx,
+__device__ __forceinline__ void walk_bvh(const float4 *__restrict__ blocks, BvhStackEntry *__restrict__ stack, uint32_t root, f3 org, f3 dir, int idx,
                                          float &tmin, int &best, uint32_t &best_rec, uint32_t &best_j, uint32_t &n_tri, uint32_t &n_tri_u) {
 	// 1/d, or +-2^100 where |d| < 2^-100: (lo - o) * inv stays finite (no 0 * inf = NaN), and keeps its sign
 	f3 inv;
 	inv.x = dm_fabs(dir.x) >= 0x1p-100f ? 1.0f / dir.x : __builtin_copysignf(0x1p100f, dir.x);
 	inv.y = dm_fabs(dir.y) >= 0x1p-100f ? 1.0f / dir.y : __builtin_copysignf(0x1p100f, dir.y);
 	inv.z = dm_fabs(dir.z) >= 0x1p-100f ? 1.0f / dir.z : __builtin_copysignf(0x1p100f, dir.z);
-	const float4 *__restrict__ n4 = reinterpret_cast<const float4 *>(nodes);
-	const float4 *__restrict__ r4 = reinterpret_cast<const float4 *>(recs);
-	// the copy of the hierarchy that is ordered front to back for this ray's sign pattern (srt_abi.hip emit_octant)
-	const uint32_t oct = (f2u(dir.x) >> 31) | ((f2u(dir.y) >> 31) << 1) | ((f2u(dir.z) >> 31) << 2);
-	uint32_t node = root0 + oct * nodes_per_octant;
-	while (node != SRT_BVH_END) {
-		const float4 a = n4[2u * node], b = n4[2u * node + 1u];
-		const float x1 = (a.x - org.x) * inv.x, x2 = (b.x - org.x) * inv.x;
-		const float y1 = (a.y - org.y) * inv.y, y2 = (b.y - org.y) * inv.y;
-		const float z1 = (a.z - org.z) * inv.z, z2 = (b.z - org.z) * inv.z;
-		const float tn = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(x1, x2), __builtin_fminf(y1, y2)), __builtin_fmaxf(__builtin_fminf(z1, z2), 0.0f));
-		const float tf = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(x1, x2), __builtin_fmaxf(y1, y2)), __builtin_fminf(__builtin_fmaxf(z1, z2), tmin));
-		const bool inside = tn <= tf * 1.000001f;
-		const uint32_t skip = f2u(a.w), leaf = f2u(b.w);
-		if (inside && leaf != 0u) {
-			const uint32_t first = leaf & 0x0fffffffu, cnt = leaf >> 28;
+	uint32_t cur = root;
+	uint32_t top_ref = SRT_BVH_NONE; // the youngest waiting entry; stack[0 .. sp) the older ones
+	float top_t = 0.0f;
+	uint32_t sp = 0u;
+	while (cur != SRT_BVH_NONE) {
+		const float4 *__restrict__ b = blocks + 8u * (size_t)(cur & SRT_BVH_INDEX_MASK);
+		const float4 q0 = b[0], q1 = b[1], q2 = b[2], q3 = b[3], q4 = b[4], q5 = b[5], q6 = b[6], q7 = b[7];
+		uint32_t next = SRT_BVH_NONE;
+		if (cur & SRT_BVH_LEAF_BIT) {
+			const uint32_t cnt = (cur >> 28) & 3u, rec0 = (cur & SRT_BVH_INDEX_MASK) << 2;
 			if (COUNT_TRIS) n_tri += cnt;
-			for (uint32_t k = 0; k < cnt; k++) {
-				const float4 q0 = r4[3u * (first + k)], q1 = r4[3u * (first + k) + 1u], q2 = r4[3u * (first + k) + 2u];
+			auto tri = [&](float v0x, float v0y, float v0z, float e1x, float e1y, float e1z, float e2x, float e2y, float e2z, float jf, uint32_t k) {
 				float t = 0.0f;
-				if (moller_trumbore<COUNT_TRIS>(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, org, dir, true, t, n_tri_u)) {
-					const uint32_t j = f2u(q2.y);
+				if (moller_trumbore<COUNT_TRIS>(v0x, v0y, v0z, e1x, e1y, e1z, e2x, e2y, e2z, org, dir, true, t, n_tri_u)) {
+					const uint32_t j = f2u(jf);
 					if (t < tmin || (t == tmin && best == idx && j < best_j)) {
 						tmin = t;
 						best = idx;
-						best_rec = first + k;
+						best_rec = rec0 + k;
 						best_j = j;
 					}
 				}
+			};
+			tri(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, 0u);
+			if (cnt > 1u) tri(q2.z, q2.w, q3.x, q3.y, q3.z, q3.w, q4.x, q4.y, q4.z, q4.w, 1u);
+			if (cnt > 2u) tri(q5.x, q5.y, q5.z, q5.w, q6.x, q6.y, q6.z, q6.w, q7.x, q7.y, 2u);
+		} else {
+			float t0, t1, t2, t3;
+			uint32_t r0, r1, r2, r3;
+			bvh_child(q0.x, q1.x, q2.x, q3.x, q4.x, q5.x, f2u(q6.x), org, inv, tmin, t0, r0);
+			bvh_child(q0.y, q1.y, q2.y, q3.y, q4.y, q5.y, f2u(q6.y), org, inv, tmin, t1, r1);
+			bvh_child(q0.z, q1.z, q2.z, q3.z, q4.z, q5.z, f2u(q6.z), org, inv, tmin, t2, r2);
+			bvh_child(q0.w, q1.w, q2.w, q3.w, q4.w, q5.w, f2u(q6.w), org, inv, tmin, t3, r3);
+			bvh_order2(t0, r0, t1, r1);
+			bvh_order2(t2, r2, t3, r3);
+			bvh_order2(t0, r0, t2, r2);
+			bvh_order2(t1, r1, t3, r3);
+			bvh_order2(t1, r1, t2, r2); // nearest first; misses (t = inf, ref = NONE) last
+			next = r0;
+			// the others wait, farthest pushed first
+			auto push = [&](uint32_t r, float t) {
+				if (r != SRT_BVH_NONE) {
+					if (top_ref != SRT_BVH_NONE) {
+						stack[sp].ref = top_ref, stack[sp].t = top_t;
+						sp++;
+					}
+					top_ref = r, top_t = t;
+				}
+			};
+			push(r3, t3);
+			push(r2, t2);
+			push(r1, t1);
+		}
+		// nothing nearer to enter: the youngest waiting child that the closest hit so far has not put out of reach
+		while (next == SRT_BVH_NONE && top_ref != SRT_BVH_NONE) {
+			if (top_t <= tmin * 1.000001f) next = top_ref;
+			if (sp > 0u) {
+				sp--;
+				top_ref = stack[sp].ref, top_t = stack[sp].t;
+			} else {
+				top_ref = SRT_BVH_NONE;
 			}
 		}
-		node = (inside && leaf == 0u) ? node + 1u : skip;
+		cur = next;
 	}
 }
 
@@ -762,7 +825,9 @@ __global__ __launch_bounds__(64, USE_BVH ? SRT_TRACE_WAVES_PER_SIMD_BVH : HAS_MO
 	uint32_t item = 0;
 	int bounce = 0;
 	int best = -1;
-	uint32_t best_tri = 0; // index inside the model; with a BVH: absolute triangle record
+	uint32_t best_tri = 0; // index inside the model; with a BVH: (leaf block << 2) | slot
+	BvhStackEntry bvh_stack[USE_BVH ? SRT_BVH_STACK_CAP : 1]; // per lane, in scratch memory (walk_bvh)
+	const float4 *__restrict__ bvh_blocks = reinterpret_cast<const float4 *>(p.bvh_blocks);
 	uint32_t best_j = 0;   // BVH only: index inside the model
 	bool active = false;   // the lane holds a ray that awaits closest_intersection
 	float tmin = DM_INF_F; // closest hit so far of the ray under way (kept across a suspension)
@@ -854,8 +919,7 @@ __global__ __launch_bounds__(64, USE_BVH ? SRT_TRACE_WAVES_PER_SIMD_BVH : HAS_MO
 							}
 							if (scan0) {
 								if (USE_BVH) {
-									if (f2u(b.v[7]) != 0u)
-										walk_bvh<COUNT_TRIS>(p.bvh_nodes, p.bvh_tris, f2u(b.v[3]), f2u(b.v[7]), org, dir, base, tmin, best, best_tri, best_j, n_tri, n_tri_u);
+									walk_bvh<COUNT_TRIS>(bvh_blocks, bvh_stack, f2u(b.v[3]), org, dir, base, tmin, best, best_tri, best_j, n_tri, n_tri_u);
 								} else {
 									if (COUNT_TRIS) n_tri += f2u(b.v[7]);
 									test_triangles<COUNT_TRIS>(wtris, f2u(b.v[3]), f2u(b.v[7]), org, dir, base, tmin, best, best_tri, n_tri_u);
@@ -863,8 +927,7 @@ __global__ __launch_bounds__(64, USE_BVH ? SRT_TRACE_WAVES_PER_SIMD_BVH : HAS_MO
 							}
 							if (((code >> 2) & 7u) > 1u && on && test_aabb(b.v[8], b.v[9], b.v[10], b.v[12], b.v[13], b.v[14], org, inv, tmin)) {
 								if (USE_BVH) {
-									if (f2u(b.v[15]) != 0u)
-										walk_bvh<COUNT_TRIS>(p.bvh_nodes, p.bvh_tris, f2u(b.v[11]), f2u(b.v[15]), org, dir, base + 1, tmin, best, best_tri, best_j, n_tri, n_tri_u);
+									walk_bvh<COUNT_TRIS>(bvh_blocks, bvh_stack, f2u(b.v[11]), org, dir, base + 1, tmin, best, best_tri, best_j, n_tri, n_tri_u);
 								} else {
 									if (COUNT_TRIS) n_tri += f2u(b.v[15]);
 									test_triangles<COUNT_TRIS>(wtris, f2u(b.v[11]), f2u(b.v[15]), org, dir, base + 1, tmin, best, best_tri, n_tri_u);
@@ -1022,7 +1085,7 @@ __global__ __launch_bounds__(64, USE_BVH ? SRT_TRACE_WAVES_PER_SIMD_BVH : HAS_MO
 					nrm = wv;
 				} else if (HAS_MODELS) {
 					const srt_model *__restrict__ m = &p.shapes[best].shape.model;
-					const float *__restrict__ w = USE_BVH ? p.bvh_tris + (size_t)best_tri * SRT_BVH_TRI_FLOATS
+					const float *__restrict__ w = USE_BVH ? p.bvh_blocks + (size_t)(best_tri >> 2) * 32u + (best_tri & 3u) * SRT_BVH_TRI_FLOATS
 					                                      : wtris + (size_t)(first_wtri + best_tri) * SRT_WTRI_FLOATS;
 					const uint32_t tri_in_model = USE_BVH ? best_j : best_tri;
 					f3 v0 = mk(w[0], w[1], w[2]);
@@ -1378,11 +1441,13 @@ __global__ __launch_bounds__(256) void srt_prepass_kernel(const PrepassParams p)
 		f3 p1 = mat_by_vec(m->transform, ld3(t->vertices[1].pos), 1.0f);
 		f3 p2 = mat_by_vec(m->transform, ld3(t->vertices[2].pos), 1.0f);
 		f3 e1 = p1 - p0, e2 = p2 - p0;
-		float *w = p.wtris + (size_t)(base + s) * (p.order ? SRT_BVH_TRI_FLOATS : SRT_WTRI_FLOATS);
+		// BVH layout: record base + s lives in slot (dest & 3) of leaf block (dest >> 2)
+		float *w = p.order ? p.wtris + (size_t)(p.dest[base + s] >> 2) * 32u + (p.dest[base + s] & 3u) * SRT_BVH_TRI_FLOATS
+		                   : p.wtris + (size_t)(base + s) * SRT_WTRI_FLOATS;
 		w[0] = p0.x, w[1] = p0.y, w[2] = p0.z;
 		w[3] = e1.x, w[4] = e1.y, w[5] = e1.z;
 		w[6] = e2.x, w[7] = e2.y, w[8] = e2.z;
-		if (p.order) w[9] = dm_u2f(j), w[10] = 0.0f, w[11] = 0.0f;
+		if (p.order) w[9] = dm_u2f(j);
 	}
 }
 

@@ -41,6 +41,7 @@ struct BvhBuilder {
 	std::vector<uint32_t> &order;
 	uint32_t rec_base = 0;
 	uint32_t leaves = 0, max_depth = 0;
+	uint32_t sah_depth = 48; // below this depth: median splits (0 = a balanced tree, see fold_wide's stack bound)
 
 	BvhBuilder(std::vector<BvhNode> &n, std::vector<uint32_t> &o) : nodes(n), order(o) {}
 
@@ -122,7 +123,7 @@ struct BvhBuilder {
 		constexpr int NB = 16;
 		int best_axis = -1, best_bin = 0;
 		float best_cost = INFINITY;
-		if (depth < 48) {
+		if (depth < sah_depth) {
 			for (int a = 0; a < 3; a++) {
 				const float ext = chi[a] - clo[a];
 				if (!(ext > 0.0f) || !std::isfinite(ext)) continue;
@@ -210,60 +211,80 @@ struct BvhBuilder {
 		}
 	}
 
-	// One octant's copy of a hierarchy. `c` is the canonical form build() leaves: depth-first, the left child (lower
-	// centroids along the split axis) directly behind its parent, the right child at the left one's skip link; indices
-	// relative to the model. The copy is appended to `out` (absolute links) in the depth-first order in which a ray whose
-	// direction has the sign pattern `oct` (bit a set = negative along axis a) meets the NEARER child of each pair first:
-	// the two children are compared along the axis on which their box centres differ most.
-	static void emit_octant(const std::vector<BvhNode> &c, int oct, uint32_t rec_off, std::vector<BvhNode> &out) {
-		if (c.empty()) return;
-		const size_t start = out.size();
-		struct Frame {
-			uint32_t ci;   // canonical node
-			uint32_t self; // its copy in out; ~0u = not emitted yet
-			uint32_t second;
-			int stage;
-		};
-		std::vector<Frame> stack;
-		stack.push_back({0u, ~0u, 0u, 0});
-		while (!stack.empty()) {
-			Frame &f = stack.back();
-			if (f.stage == 0) {
-				f.self = (uint32_t)out.size();
-				out.push_back(c[f.ci]);
-				if (c[f.ci].leaf) {
-					out[f.self].leaf = c[f.ci].leaf + rec_off;
-					out[f.self].skip = (uint32_t)out.size();
-					stack.pop_back();
-					continue;
-				}
-				const uint32_t left = f.ci + 1u, right = c[left].skip;
-				int axis = 0;
-				float best = -1.0f, delta = 0.0f;
-				for (int a = 0; a < 3; a++) {
-					const float d = (0.5f * c[right].lo[a] + 0.5f * c[right].hi[a]) - (0.5f * c[left].lo[a] + 0.5f * c[left].hi[a]);
-					if (std::isfinite(d) && std::fabs(d) > best) best = std::fabs(d), axis = a, delta = d;
-				}
-				const bool negative_dir = (oct >> axis) & 1;
-				const bool left_first = (delta >= 0.0f) != negative_dir; // right lies further along +axis: nearer for a ray going the negative way
-				f.second = left_first ? right : left;
-				f.stage = 1;
-				const uint32_t first = left_first ? left : right;
-				stack.push_back({first, ~0u, 0u, 0}); // invalidates f
-				continue;
-			}
-			if (f.stage == 1) {
-				f.stage = 2;
-				const uint32_t second = f.second;
-				stack.push_back({second, ~0u, 0u, 0});
-				continue;
-			}
-			out[f.self].skip = (uint32_t)out.size();
-			stack.pop_back();
+	// The wide form of a hierarchy (device_types.h): `c` is the canonical binary form build() leaves (depth-first, the left
+	// child directly behind its parent, the right one at the left one's skip link; indices and records relative to the
+	// model). An inner block takes the two children of a node and then, while it has room, replaces the child with the
+	// largest box by that child's own two (`balanced`: the node's grandchildren, level by level); leaves become leaf
+	// blocks. Blocks are appended to `out` (32 dwords each, block indices relative to `out`'s start = the model's first
+	// block), `inner` lists the inner ones (their references are shifted when the model is placed in the scene), dest[r]
+	// = (leaf block << 2) | slot of record r. Returns the root reference and in `need` the most entries a walk can have
+	// waiting at once: every block on the way down leaves at most (children - 1) behind.
+	struct Wide {
+		std::vector<uint32_t> blocks;
+		std::vector<uint32_t> inner;
+		std::vector<uint32_t> dest;
+		uint32_t root = SRT_BVH_NONE, need = 0;
+	};
+	static uint32_t fold_node(const std::vector<BvhNode> &c, uint32_t ci, bool balanced, Wide &w, uint32_t &need) {
+		const BvhNode &nd = c[ci];
+		const uint32_t self = (uint32_t)(w.blocks.size() / 32);
+		w.blocks.resize(w.blocks.size() + 32, 0u);
+		if (nd.leaf) {
+			const uint32_t first = nd.leaf & 0x0fffffffu, cnt = nd.leaf >> 28;
+			for (uint32_t k = 0; k < cnt; k++) w.dest[first + k] = (self << 2) | k;
+			need = 0;
+			return SRT_BVH_LEAF_BIT | (cnt << 28) | self;
 		}
-		const uint32_t end = (uint32_t)out.size();
-		for (size_t i = start; i < out.size(); i++)
-			if (out[i].skip == end) out[i].skip = SRT_BVH_END;
+		w.inner.push_back(self);
+		uint32_t kids[4], nk = 0;
+		const uint32_t left = ci + 1u, right = c[left].skip;
+		kids[nk++] = left, kids[nk++] = right;
+		if (balanced) {
+			uint32_t g[4], ng = 0;
+			for (uint32_t k = 0; k < 2; k++)
+				if (c[kids[k]].leaf) g[ng++] = kids[k];
+				else g[ng++] = kids[k] + 1u, g[ng++] = c[kids[k] + 1u].skip;
+			nk = ng;
+			for (uint32_t k = 0; k < ng; k++) kids[k] = g[k];
+		} else {
+			while (nk < 4) {
+				int open = -1;
+				float area = -1.0f;
+				for (uint32_t k = 0; k < nk; k++) {
+					if (c[kids[k]].leaf) continue;
+					const float a = half_area(c[kids[k]].lo, c[kids[k]].hi);
+					if (open < 0 || a > area) open = (int)k, area = a; // NaN / inf areas (hostile input) still pick somebody
+				}
+				if (open < 0) break;
+				const uint32_t o = kids[open];
+				kids[open] = o + 1u;
+				kids[nk++] = c[o + 1u].skip;
+			}
+		}
+		uint32_t deepest = 0;
+		for (uint32_t k = 0; k < nk; k++) {
+			uint32_t sub = 0;
+			const uint32_t ref = fold_node(c, kids[k], balanced, w, sub); // may grow w.blocks: index, do not keep pointers
+			if (sub > deepest) deepest = sub;
+			uint32_t *blk = w.blocks.data() + 32 * (size_t)self;
+			const BvhNode &kid = c[kids[k]];
+			for (int a = 0; a < 3; a++) {
+				memcpy(&blk[8 * a + k], &kid.lo[a], 4);
+				memcpy(&blk[8 * a + 4 + k], &kid.hi[a], 4);
+			}
+			blk[24 + k] = ref;
+		}
+		for (uint32_t k = nk; k < 4; k++) w.blocks[32 * (size_t)self + 24 + k] = SRT_BVH_NONE;
+		need = deepest + (nk - 1u);
+		return ref_of_inner(self);
+	}
+	static uint32_t ref_of_inner(uint32_t block) { return block; }
+	static void fold_wide(const std::vector<BvhNode> &c, uint32_t records, bool balanced, Wide &w) {
+		w.blocks.clear(), w.inner.clear();
+		w.dest.assign(records, 0u);
+		w.root = SRT_BVH_NONE, w.need = 0;
+		if (c.empty()) return;
+		w.root = fold_node(c, 0u, balanced, w, w.need);
 	}
 
 	// Appends the model's nodes and triangle order; returns the root's index.
@@ -292,7 +313,28 @@ struct BvhCacheEntry {
 	std::vector<srt_triangle> tris;
 	std::vector<BvhNode> nodes;
 	std::vector<uint32_t> order;
+	BvhBuilder::Wide wide; // what the device walks, block indices relative to the model's first block
+	bool balanced = false; // built without the SAH because the SAH tree could overflow a lane's stack
 	uint32_t leaves = 0, depth = 0;
+	// (re)builds nodes/order from the model and folds them; the fallback keeps every walk inside SRT_BVH_STACK_CAP
+	void build(const srt_model &m, const srt_triangle *all) {
+		for (int attempt = balanced ? 1 : 0; attempt < 2; attempt++) {
+			nodes.clear(), order.clear();
+			BvhBuilder bb(nodes, order);
+			if (attempt) bb.sah_depth = 0;
+			bb.run(m, all, 0u);
+			leaves = bb.leaves, depth = bb.max_depth;
+			balanced = attempt != 0;
+			BvhBuilder::fold_wide(nodes, m.num_triangles, balanced, wide);
+			if (wide.need <= SRT_BVH_STACK_CAP) break; // a balanced tree of < 2^28 triangles needs at most 3 * 15
+		}
+	}
+	void refit(const srt_model &m, const srt_triangle *all) {
+		BvhBuilder bb(nodes, order);
+		bb.refit(m, all);
+		BvhBuilder::fold_wide(nodes, m.num_triangles, balanced, wide);
+		if (wide.need > SRT_BVH_STACK_CAP) build(m, all); // the new boxes fold differently: start over
+	}
 	bool same_triangles(const srt_model &m, const srt_triangle *all, uint64_t hash) const {
 		return m.num_triangles == count && hash == tri_hash && memcmp(tris.data(), all + m.triangle_index, (size_t)count * sizeof(srt_triangle)) == 0;
 	}
@@ -447,9 +489,9 @@ void srt_destroy(srt_tracer *t) {
 	t->materials.release();
 	t->wtris.release();
 	t->wtri_offset.release();
-	t->bvh_nodes.release();
+	t->bvh_blocks.release();
 	t->bvh_order.release();
-	t->bvh_tris.release();
+	t->bvh_dest.release();
 	t->sky.release();
 	t->counters.release();
 	t->wave_counters.release();
@@ -514,8 +556,8 @@ static int update_scene_impl(srt_tracer *t, const srt_shape *shapes, size_t n_sh
 	uint64_t total_wtris = 0, max_tris = 0;
 	int num_models = 0;
 	const bool use_bvh = t->accel_mode == SRT_ACCEL_BVH;
-	std::vector<BvhNode> bvh_nodes;
-	std::vector<uint32_t> bvh_order;
+	std::vector<uint32_t> bvh_blocks; // 32 dwords each (device_types.h)
+	std::vector<uint32_t> bvh_order, bvh_dest;
 	uint64_t bvh_leaves = 0, bvh_depth = 0, bvh_reused = 0, bvh_refitted = 0, bvh_canonical_nodes = 0;
 	std::deque<BvhCacheEntry> fresh;                 // hierarchies built by this call (deque: growth keeps references valid)
 	std::vector<std::pair<bool, size_t>> plan;       // per model with triangles: {from the cache?, index there / in fresh}
@@ -583,8 +625,7 @@ static int update_scene_impl(srt_tracer *t, const srt_shape *shapes, size_t n_sh
 			}
 			if (total_wtris + m.num_triangles > (use_bvh ? 0x0fffffffull : 0xffffffffull))
 				return fail(t, SRT_ERR_INVALID, "srt_update_scene: too many world triangles");
-			uint32_t link = (uint32_t)total_wtris; // brute force: first world triangle of the model
-			uint32_t bvh_npo = 0;                  // BVH: nodes per octant copy (0 = a model without triangles: nothing to walk)
+			uint32_t link = use_bvh ? SRT_BVH_NONE : (uint32_t)total_wtris; // first world triangle of the model; BVH: root reference (NONE = nothing to walk)
 			if (use_bvh && m.num_triangles > 0) {
 				// hash of this triangle range, once per distinct range per call (instances share ranges)
 				uint64_t th = 0;
@@ -615,8 +656,7 @@ static int update_scene_impl(srt_tracer *t, const srt_shape *shapes, size_t n_sh
 					if (ent->same_transform(m)) {
 						bvh_reused++;
 					} else { // the model moved: keep the topology, recompute the boxes
-						BvhBuilder bb(ent->nodes, ent->order);
-						bb.refit(m, triangles);
+						ent->refit(m, triangles);
 						memcpy(ent->transform, m.transform, sizeof ent->transform);
 						bvh_refitted++;
 					}
@@ -624,32 +664,35 @@ static int update_scene_impl(srt_tracer *t, const srt_shape *shapes, size_t n_sh
 				} else {
 					fresh.emplace_back();
 					ent = &fresh.back();
-					BvhBuilder bb(ent->nodes, ent->order);
-					bb.run(m, triangles, 0u);
+					ent->build(m, triangles);
 					ent->count = m.num_triangles;
 					ent->tri_hash = th;
 					memcpy(ent->transform, m.transform, sizeof ent->transform);
 					ent->tris.assign(triangles + m.triangle_index, triangles + m.triangle_index + m.num_triangles);
-					ent->leaves = bb.leaves, ent->depth = bb.max_depth;
 					plan.emplace_back(false, fresh.size() - 1);
 				}
-				// Indices inside an entry are relative to its first node / first record. The device gets the hierarchy
-				// EIGHT times, once per sign pattern of a ray's direction: the same nodes, in the depth-first order in
-				// which that pattern meets the nearer child of every pair first (emit_octant). A lane walks the copy of
-				// its ray's octant, so its closest hit tends to come early and the skip links jump over what lies behind.
-				const uint32_t n0 = (uint32_t)bvh_nodes.size(), r0 = (uint32_t)total_wtris;
-				if ((uint64_t)n0 + 8ull * ent->nodes.size() >= 0xffffffffull) return fail(t, SRT_ERR_INVALID, "srt_update_scene: too many BVH nodes");
-				bvh_nodes.reserve(bvh_nodes.size() + 8 * ent->nodes.size());
-				for (int oct = 0; oct < 8; oct++) BvhBuilder::emit_octant(ent->nodes, oct, r0, bvh_nodes); // r0 + records < 2^28 (checked above)
+				// Indices inside an entry are relative to the model's first block / first record: shift them to where the
+				// model lands in the scene's arrays.
+				const uint32_t b0 = (uint32_t)(bvh_blocks.size() / 32), r0 = (uint32_t)total_wtris;
+				const BvhBuilder::Wide &wd = ent->wide;
+				if ((uint64_t)b0 + wd.blocks.size() / 32 > SRT_BVH_INDEX_MASK) return fail(t, SRT_ERR_INVALID, "srt_update_scene: too many BVH blocks");
+				if (wd.need > SRT_BVH_STACK_CAP) return fail(t, SRT_ERR_INVALID, "srt_update_scene: BVH deeper than the walk's stack"); // unreachable below 2^28 triangles
+				bvh_blocks.insert(bvh_blocks.end(), wd.blocks.begin(), wd.blocks.end());
+				for (uint32_t ib : wd.inner)
+					for (int k = 0; k < 4; k++) {
+						uint32_t &ref = bvh_blocks[32 * (size_t)(b0 + ib) + 24 + k];
+						if (ref != SRT_BVH_NONE) ref += b0;
+					}
+				bvh_dest.resize(r0 + (size_t)m.num_triangles);
+				for (uint32_t r = 0; r < m.num_triangles; r++) bvh_dest[r0 + r] = wd.dest[r] + (b0 << 2);
 				bvh_canonical_nodes += ent->nodes.size();
 				bvh_order.insert(bvh_order.end(), ent->order.begin(), ent->order.end());
-				link = n0;                              // BVH: the root of octant 0's copy ...
-				bvh_npo = (uint32_t)ent->nodes.size();  // ... and the distance to the next octant's
+				link = wd.root == SRT_BVH_NONE ? SRT_BVH_NONE : wd.root + b0; // the root reference (a leaf reference for a model of <= 3 triangles)
 				bvh_leaves += ent->leaves;
 				if (ent->depth > bvh_depth) bvh_depth = ent->depth;
 			}
 			data.insert(data.end(), {m.bounding_min.x, m.bounding_min.y, m.bounding_min.z, u2f(link), m.bounding_max.x, m.bounding_max.y,
-			                         m.bounding_max.z, u2f(use_bvh ? bvh_npo : m.num_triangles)});
+			                         m.bounding_max.z, u2f(use_bvh ? 0u : m.num_triangles)});
 			wr.first_wtri = (uint32_t)total_wtris;
 			offs[i] = (uint32_t)total_wtris;
 			// brute force: blocks of 4, the tail stays all-zero (never hit); BVH: records are addressed one by one
@@ -681,13 +724,15 @@ static int update_scene_impl(srt_tracer *t, const srt_shape *shapes, size_t n_sh
 	SRT_HIP(t, t->triangles.reserve(n_triangles));
 	SRT_HIP(t, t->materials.reserve(n_materials));
 	if (use_bvh) {
-		SRT_HIP(t, t->bvh_nodes.reserve(bvh_nodes.size()));
+		SRT_HIP(t, t->bvh_blocks.reserve(bvh_blocks.size()));
 		SRT_HIP(t, t->bvh_order.reserve(bvh_order.size()));
-		SRT_HIP(t, t->bvh_tris.reserve((size_t)total_wtris * SRT_BVH_TRI_FLOATS));
-		if (!bvh_nodes.empty())
-			SRT_HIP(t, hipMemcpyAsync(t->bvh_nodes.ptr, bvh_nodes.data(), bvh_nodes.size() * sizeof(BvhNode), hipMemcpyHostToDevice, t->stream));
-		if (!bvh_order.empty())
+		SRT_HIP(t, t->bvh_dest.reserve(bvh_dest.size()));
+		if (!bvh_blocks.empty()) // inner blocks complete, leaf blocks zero: srt_prepass_kernel writes their triangles
+			SRT_HIP(t, hipMemcpyAsync(t->bvh_blocks.ptr, bvh_blocks.data(), bvh_blocks.size() * sizeof(uint32_t), hipMemcpyHostToDevice, t->stream));
+		if (!bvh_order.empty()) {
 			SRT_HIP(t, hipMemcpyAsync(t->bvh_order.ptr, bvh_order.data(), bvh_order.size() * sizeof(uint32_t), hipMemcpyHostToDevice, t->stream));
+			SRT_HIP(t, hipMemcpyAsync(t->bvh_dest.ptr, bvh_dest.data(), bvh_dest.size() * sizeof(uint32_t), hipMemcpyHostToDevice, t->stream));
+		}
 	} else {
 		SRT_HIP(t, t->wtris.reserve((size_t)total_wtris * SRT_WTRI_FLOATS + 64)); // + slack for the loop's look-ahead pair
 	}
@@ -729,8 +774,9 @@ static int update_scene_impl(srt_tracer *t, const srt_shape *shapes, size_t n_sh
 			pp.shapes = t->shapes.ptr + base;
 			pp.triangles = t->triangles.ptr;
 			pp.wtri_offset = t->wtri_offset.ptr + base;
-			pp.wtris = use_bvh ? t->bvh_tris.ptr : t->wtris.ptr;
+			pp.wtris = use_bvh ? reinterpret_cast<float *>(t->bvh_blocks.ptr) : t->wtris.ptr;
 			pp.order = use_bvh ? t->bvh_order.ptr : nullptr;
+			pp.dest = use_bvh ? t->bvh_dest.ptr : nullptr;
 			size_t cnt = n_shapes - base;
 			pp.num_shapes = (int32_t)(cnt > 65535 ? 65535 : cnt);
 			pp.num_triangles = (uint32_t)n_triangles;
@@ -802,8 +848,7 @@ int srt_trace(srt_tracer *t, const srt_render_data *options) {
 	p.sun_focus_int = dm_pow_small_int(p.sd.sun_focus);
 	p.num_models = t->num_models;
 	p.use_bvh = t->bvh_active ? 1 : 0;
-	p.bvh_nodes = t->bvh_nodes.ptr;
-	p.bvh_tris = t->bvh_tris.ptr;
+	p.bvh_blocks = reinterpret_cast<const float *>(t->bvh_blocks.ptr);
 	p.rank = t->rank;
 	p.world = t->world;
 	p.rows_per_block = t->rows_per_block;
@@ -1187,6 +1232,27 @@ int srt_bvh_build_host(const srt_shape *model, const srt_triangle *triangles, si
 		*n_nodes = nodes.size();
 		if (nodes_out) memcpy(nodes_out, nodes.data(), std::min(nodes.size(), nodes_cap) * sizeof(BvhNode));
 		if (order_out) memcpy(order_out, order.data(), std::min(order.size(), order_cap) * sizeof(uint32_t));
+	} catch (...) { // std::bad_alloc: no C++ exception may cross the C ABI
+		return SRT_ERR_INVALID;
+	}
+	return SRT_OK;
+}
+
+int srt_bvh_wide_host(const srt_shape *model, const srt_triangle *triangles, size_t n_triangles, int force_balanced, uint32_t *blocks_out,
+                      size_t blocks_cap, uint32_t *dest_out, size_t dest_cap, size_t *n_blocks, uint32_t *root, uint32_t *stack_need, int *balanced) {
+	if (!model || !n_blocks || model->type != SRT_SHAPE_MODEL || (n_triangles && !triangles)) return SRT_ERR_INVALID;
+	const srt_model &m = model->shape.model;
+	if ((uint64_t)m.triangle_index + m.num_triangles > n_triangles || m.num_triangles > 0x0fffffffu) return SRT_ERR_INVALID;
+	try {
+		BvhCacheEntry ent;
+		ent.balanced = force_balanced != 0;
+		if (m.num_triangles > 0) ent.build(m, triangles);
+		*n_blocks = ent.wide.blocks.size() / 32;
+		if (root) *root = ent.wide.root;
+		if (stack_need) *stack_need = ent.wide.need;
+		if (balanced) *balanced = ent.balanced ? 1 : 0;
+		if (blocks_out) memcpy(blocks_out, ent.wide.blocks.data(), std::min(ent.wide.blocks.size(), blocks_cap * 32) * sizeof(uint32_t));
+		if (dest_out) memcpy(dest_out, ent.wide.dest.data(), std::min(ent.wide.dest.size(), dest_cap) * sizeof(uint32_t));
 	} catch (...) { // std::bad_alloc: no C++ exception may cross the C ABI
 		return SRT_ERR_INVALID;
 	}

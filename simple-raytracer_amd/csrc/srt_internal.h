@@ -55,9 +55,8 @@ struct srt_tracer {
 	DevBuf<float> wtris;
 	DevBuf<uint32_t> wtri_offset;
 	DevBuf<float> sky;
-	DevBuf<BvhNode> bvh_nodes;
-	DevBuf<uint32_t> bvh_order;
-	DevBuf<float> bvh_tris;
+	DevBuf<uint32_t> bvh_blocks; // wide hierarchy, 32 dwords per block (device_types.h)
+	DevBuf<uint32_t> bvh_order, bvh_dest;
 	int accel_mode = SRT_ACCEL_NONE; // what the next srt_update_scene builds
 	bool bvh_active = false;         // the current scene's models carry BVH roots
 	uint64_t bvh_info[7] = {0, 0, 0, 0, 0, 0, 0};

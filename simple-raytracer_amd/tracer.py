@@ -27,7 +27,7 @@ ABI_SYMBOLS = [
     "srt_get_counters", "srt_set_count_triangles", "srt_reset_counters", "srt_last_kernel_ms", "srt_last_trace_kernel_ms",
     "srt_device_buffers", "srt_bind_canvas", "srt_bind_stream", "srt_set_partition",
     "srt_partition_owned_rows", "srt_partition_padded_rows", "srt_partition_global_row",
-    "srt_partition_unpermute", "srt_selftest_math", "srt_version", "srt_set_acceleration", "srt_acceleration_info", "srt_bvh_build_host", "srt_debug_counters",
+    "srt_partition_unpermute", "srt_selftest_math", "srt_version", "srt_set_acceleration", "srt_acceleration_info", "srt_bvh_build_host", "srt_bvh_wide_host", "srt_debug_counters",
     "srt_comm_unique_id", "srt_comm_init", "srt_gather", "srt_resolve_gathered", "srt_gathered_buffers", "srt_read_gathered",
     "srt_group_create", "srt_group_destroy", "srt_group_last_error", "srt_group_size", "srt_group_tracer", "srt_group_set_skybox",
     "srt_group_set_acceleration", "srt_group_update_scene", "srt_group_clear_canvas", "srt_group_trace_and_gather", "srt_group_render",
@@ -58,6 +58,35 @@ def bvh_build_host(model_shape, triangles):
     if rc:
         raise SrtError(f"srt_bvh_build_host failed ({rc})")
     return nodes, order
+
+
+BVH_NONE = 0xFFFFFFFF
+BVH_LEAF_BIT = 0x80000000
+BVH_INDEX_MASK = 0x0FFFFFFF
+BVH_STACK_CAP = 64
+
+
+def bvh_wide_host(model_shape, triangles, force_balanced=False):
+    """The four-wide hierarchy the kernel walks for one model shape record (csrc/device_types.h): dict with
+    blocks (n x 32 uint32; view as float32 for the boxes), dest (per record: leaf block << 2 | slot), root,
+    stack_need, balanced. Host only: no GPU needed; leaf blocks come back empty (the device writes the triangles)."""
+    lib = load_library()
+    lib.srt_bvh_wide_host.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t,
+                                      C.POINTER(C.c_size_t), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_int)]
+    shape = np.zeros(1, R.SHAPE)
+    shape[0] = model_shape
+    tris = R.as_records(triangles, R.TRIANGLE)
+    n, root, need, bal = C.c_size_t(0), C.c_uint32(0), C.c_uint32(0), C.c_int(0)
+    rc = lib.srt_bvh_wide_host(_ptr(shape), _ptr(tris), len(tris), int(force_balanced), None, 0, None, 0, C.byref(n), None, None, None)
+    if rc:
+        raise SrtError(f"srt_bvh_wide_host failed ({rc})")
+    blocks = np.zeros((n.value, 32), np.uint32)
+    dest = np.zeros(int(shape[0]["num_triangles"]), np.uint32)
+    rc = lib.srt_bvh_wide_host(_ptr(shape), _ptr(tris), len(tris), int(force_balanced), _ptr(blocks), len(blocks), _ptr(dest), len(dest),
+                               C.byref(n), C.byref(root), C.byref(need), C.byref(bal))
+    if rc:
+        raise SrtError(f"srt_bvh_wide_host failed ({rc})")
+    return {"blocks": blocks, "dest": dest, "root": root.value, "stack_need": need.value, "balanced": bool(bal.value)}
 
 
 class Counters(C.Structure):

@@ -1,14 +1,16 @@
 """CPU: the host-side BVH builder behind srt_set_acceleration, through the host-only entry
-point srt_bvh_build_host (no GPU involved). Structure invariants the stackless walk relies on,
-box containment, and a float32 re-enactment of the walk against a brute-force double-precision
-Moller-Trumbore: every triangle a ray really hits must be among the triangles the walk tests."""
+points srt_bvh_build_host (the binary hierarchy that is built, cached and refitted) and
+srt_bvh_wide_host (its four-wide folding, which the kernel walks); no GPU involved. Structure
+invariants, box containment, the bound on a walk's stack, and a float32 re-enactment of the walk
+against a brute-force double-precision Moller-Trumbore: every triangle a ray really hits must be
+among the triangles the walk tests."""
 import numpy as np
 import pytest
 
 from simple_raytracer_amd import records as R, scenes as S, tracer as T
 
 END = T.BVH_END
-LEAF_MAX = 2  # SRT_BVH_LEAF_MAX (csrc/device_types.h)
+LEAF_MAX = 3  # SRT_BVH_LEAF_MAX (csrc/device_types.h)
 
 
 def world_vertices(shape, tris):
@@ -56,25 +58,90 @@ def check_boxes(nodes, order, wv):
         assert (v.min(axis=0) > nodes["lo"][i]).all() and (v.max(axis=0) < nodes["hi"][i]).all(), "boxes are padded"
 
 
-def walk(nodes, org, d):
-    """The device's walk (csrc/kernels.hip walk_bvh) with tmin = inf, in float32; returns the tested records."""
+def check_wide(wide, nodes, order, n_tris):
+    """Every record sits in exactly one slot of one leaf block, references are in range and each block is referenced
+    once, the four boxes of an inner block are boxes of the binary hierarchy, and no walk can have more than
+    stack_need (<= the kernel's 64) children waiting. Returns (inner blocks, leaf blocks)."""
+    blocks, dest, root = wide["blocks"], wide["dest"], wide["root"]
+    if n_tris == 0:
+        assert root == T.BVH_NONE and len(blocks) == 0
+        return 0, 0
+    fl = blocks.view(np.float32)
+    seen = np.zeros(len(blocks), np.int32)
+    slots = {}
+    boxes = {(tuple(nd["lo"]), tuple(nd["hi"])) for nd in nodes}
+    inner = leaves = 0
+
+    def need_of(ref):
+        nonlocal inner, leaves
+        idx = ref & T.BVH_INDEX_MASK
+        assert idx < len(blocks)
+        seen[idx] += 1
+        if ref & T.BVH_LEAF_BIT:
+            cnt = (ref >> 28) & 3
+            assert 1 <= cnt <= LEAF_MAX
+            assert not blocks[idx].any(), "leaf blocks arrive empty: the device writes the triangles"
+            for k in range(cnt):
+                slots[(idx << 2) | k] = slots.get((idx << 2) | k, 0) + 1
+            leaves += 1
+            return 0
+        inner += 1
+        refs = [int(r) for r in blocks[idx, 24:28]]
+        kids = [r for r in refs if r != T.BVH_NONE]
+        assert 2 <= len(kids) <= 4 and refs[:len(kids)] == kids, "children are packed to the front"
+        assert not blocks[idx, 28:].any()
+        for k in range(len(kids)):
+            lo = tuple(fl[idx, [k, 8 + k, 16 + k]])
+            hi = tuple(fl[idx, [4 + k, 12 + k, 20 + k]])
+            assert (lo, hi) in boxes
+        return len(kids) - 1 + max(need_of(r) for r in kids)
+
+    import sys
+    sys.setrecursionlimit(10000)
+    need = need_of(root)
+    assert (seen == 1).all(), "every block hangs off exactly one reference"
+    assert sorted(slots) == sorted(dest.tolist()) and all(v == 1 for v in slots.values()) and len(dest) == n_tris
+    assert need == wide["stack_need"] <= T.BVH_STACK_CAP
+    return inner, leaves
+
+
+def walk(wide, rec_of_slot, org, d):
+    """The device's walk (csrc/kernels.hip walk_bvh) with tmin = inf, in float32; returns the tested records, the
+    blocks fetched and the deepest the stack got."""
     f = np.float32
     org, d = org.astype(f), d.astype(f)
     with np.errstate(all="ignore"):
         inv = np.where(np.abs(d) >= f(2.0 ** -100), f(1) / d, np.copysign(f(2.0 ** 100), d)).astype(f)
-    tested, node, steps = [], 0, 0
-    while node != END:
+    blocks = wide["blocks"]
+    fl = blocks.view(np.float32)
+    tested, steps, deepest = [], 0, 0
+    stack, cur = [], wide["root"]
+    while cur != T.BVH_NONE:
         steps += 1
-        lo, hi = nodes["lo"][node], nodes["hi"][node]
-        a1, a2 = (lo - org) * inv, (hi - org) * inv
-        tn = max(np.minimum(a1, a2).max(), f(0))
-        tf = np.maximum(a1, a2).min()
-        inside = tn <= tf * f(1.000001)
-        lf = int(nodes["leaf"][node])
-        if inside and lf:
-            tested.extend(range(lf & 0x0FFFFFFF, (lf & 0x0FFFFFFF) + (lf >> 28)))
-        node = node + 1 if (inside and not lf) else int(nodes["skip"][node])
-    return tested, steps
+        idx = cur & T.BVH_INDEX_MASK
+        nxt = T.BVH_NONE
+        if cur & T.BVH_LEAF_BIT:
+            tested.extend(rec_of_slot[(idx << 2) | k] for k in range((cur >> 28) & 3))
+        else:
+            hits = []
+            for k in range(4):
+                ref = int(blocks[idx, 24 + k])
+                lo, hi = fl[idx, [k, 8 + k, 16 + k]], fl[idx, [4 + k, 12 + k, 20 + k]]
+                with np.errstate(all="ignore"):
+                    a1, a2 = (lo - org) * inv, (hi - org) * inv
+                tn = max(np.minimum(a1, a2).max(), f(0))
+                tf = np.maximum(a1, a2).min()
+                if tn <= tf * f(1.000001) and ref != T.BVH_NONE:
+                    hits.append((tn, ref))
+            hits.sort(key=lambda h: h[0])
+            if hits:
+                nxt = hits[0][1]
+                stack.extend(r for _, r in reversed(hits[1:]))
+                deepest = max(deepest, len(stack))
+        if nxt == T.BVH_NONE and stack:
+            nxt = stack.pop()
+        cur = nxt
+    return tested, steps, deepest
 
 
 def true_hits(wv, org, d):
@@ -109,6 +176,10 @@ def test_structure_boxes_and_walk(name):
     check_structure(nodes, order, len(tris))
     wv = world_vertices(shape, tris)
     check_boxes(nodes, order, wv)
+    wide = T.bvh_wide_host(shape, tris)
+    inner, leaves = check_wide(wide, nodes, order, len(tris))
+    assert leaves == int((nodes["leaf"] != 0).sum()) and not wide["balanced"]
+    rec_of_slot = {int(s): r for r, s in enumerate(wide["dest"])}
     rng = np.random.RandomState(11)
     centre, radius = wv.reshape(-1, 3).mean(axis=0), np.abs(wv.reshape(-1, 3) - wv.reshape(-1, 3).mean(axis=0)).max() * 2.5
     n_hits = 0
@@ -119,8 +190,8 @@ def test_structure_boxes_and_walk(name):
         d /= np.linalg.norm(d)
         if k % 10 == 0:
             d[rng.randint(3)] = 0.0  # axis-parallel components exercise the safe inverse
-        tested, steps = walk(nodes, org, d)
-        assert steps <= len(nodes)
+        tested, steps, deepest = walk(wide, rec_of_slot, org, d)
+        assert steps <= len(wide["blocks"]) and deepest <= wide["stack_need"]
         hit = true_hits(wv, org, d)
         rec_of = np.empty(len(order), np.int64)
         rec_of[order] = np.arange(len(order))
@@ -141,6 +212,34 @@ def test_100k_triangle_mesh_builds_fast_and_well_formed():
     depth = check_structure(nodes, order, n)
     assert n // LEAF_MAX <= int((nodes["leaf"] != 0).sum()) <= n
     assert depth <= 64 and dt < 5.0
+    t0 = time.time()
+    wide = T.bvh_wide_host(model, tris)
+    dt = time.time() - t0
+    inner, leaves = check_wide(wide, nodes, order, n)
+    assert inner * 2 <= leaves and dt < 5.0  # four-wide: about a third as many inner blocks as leaves
+    assert len(wide["blocks"]) * 128 < 9 << 20  # the whole hierarchy, triangles included: 8.5 MB
+
+
+def test_a_hierarchy_too_deep_for_the_stack_is_rebuilt_balanced():
+    """Triangles whose sizes and spacing grow geometrically: the SAH peels them off one at a time, a chain whose walk
+    could have ~3 children waiting per level. The library must notice (stack_need) and fall back to median splits."""
+    n = 400
+    tris = np.zeros(n, R.TRIANGLE)
+    for i in range(n):
+        s, x = 1.02 ** i, 60.0 * (1.02 ** i)
+        tris[i] = R.flat_triangle((0, 0, 1), (x, 0, 0), (x + s, 0, 0), (x, s, 0))
+    shape = R.model(0, tris, 0, n)
+    nodes, order = T.bvh_build_host(shape, tris)
+    depth = check_structure(nodes, order, n)
+    wide = T.bvh_wide_host(shape, tris)
+    if depth > 70:  # the SAH tree really is a chain: only the balanced form fits
+        assert wide["balanced"]
+    assert wide["stack_need"] <= T.BVH_STACK_CAP
+    forced = T.bvh_wide_host(shape, tris, force_balanced=True)
+    assert forced["balanced"] and forced["stack_need"] <= 3 * 6  # ceil(log4(400 / 3)) + 1 levels of at most 3 waiting
+    rec_of_slot = {int(s): r for r, s in enumerate(forced["dest"])}
+    tested, steps, deepest = walk(forced, rec_of_slot, np.array([0.0, 0.1, 5.0]), np.array([1.0, 0.0, -0.001]))
+    assert deepest <= forced["stack_need"]
 
 
 def test_degenerate_inputs():
@@ -158,5 +257,8 @@ def test_degenerate_inputs():
     empty = R.model(0, tris, 0, 0)
     nodes, order = T.bvh_build_host(empty, tris)
     assert len(nodes) == 0 and len(order) == 0
+    check_wide(T.bvh_wide_host(empty, tris), nodes, order, 0)
+    nodes, order = T.bvh_build_host(shape, tris)
+    check_wide(T.bvh_wide_host(shape, tris), nodes, order, 8)
     with pytest.raises(T.SrtError):
         T.bvh_build_host(R.sphere(0, (0, 0, 0), 1.0), tris)  # not a model

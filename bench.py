@@ -213,6 +213,11 @@ def main():
         args.gpus = world
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    # stdout carries the ONE JSON line and nothing else: RCCL / gloo print banners to fd 1 when a communicator comes up
+    # ("RCCL version : ...", "[Gloo] Rank 0 is connected to ..."), so fd 1 points at stderr until the line is written
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     B.build_hip()
     rehearsal = args.backend == "gloo"
     if rehearsal:
@@ -417,7 +422,8 @@ def main():
             cb["gpu_rows_checked"] = int(sum(y1 - y0 for y0, y1 in port_rows))
             line["cpu_baseline"] = cb
             ok = ok and cb["gpu_equals_port"] and cb.get("reference_equals_port", True)
-        print(json.dumps(line), flush=True)
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(line) + "\n").encode())
         if not ok:
             t.close()
             raise SystemExit("bench.py: the timed canvas differs from its checker (see gpu_equals_port / gathered_equals_single_gpu in the line above)")

@@ -14,6 +14,7 @@ from simple_raytracer_amd.tracer import Tracer
 sky = S.synthetic_sky()
 WORK = {
     "spheres": (S.sphere_scene, 1920, 1080, 64, 0),
+    "spheres_noglass": (lambda: (lambda sh, tr, ma: (sh, tr, np.concatenate([ma[:4], ma[3:4], ma[5:]])))(*S.sphere_scene()), 1920, 1080, 64, 0),  # what the glass branch costs
     "mesh2": (lambda: S.mesh_scene(2), 1920, 1080, 8, 0),
     "mesh2_bvh": (lambda: S.mesh_scene(2), 1920, 1080, 8, 1),
     "mesh100k_bvh": (lambda: S.mesh_scene(1, 224, 224, smooth=False), 1920, 1080, 16, 1),

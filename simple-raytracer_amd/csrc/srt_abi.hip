@@ -21,6 +21,13 @@
 
 #include "srt_internal.h"
 
+#ifndef SRT_OVERLAP_BATCHES
+#define SRT_OVERLAP_BATCHES 1 // srt_trace: consecutive sample batches on two streams (0: one after the other, A/B only)
+#endif
+#ifndef SRT_SCAN_PAIRS_PER_LAUNCH
+#define SRT_SCAN_PAIRS_PER_LAUNCH 8e12 // srt_trace: ray-triangle pairs one array-scan launch may come to (sample batches)
+#endif
+
 namespace {
 
 thread_local std::string g_create_error;
@@ -455,7 +462,7 @@ int srt_create(int width, int height, int device_index, srt_tracer **out) {
 	t->canvas_bytes = px * 16;
 	if ((e = t->argb.reserve(px * 4)) != hipSuccess) return bail("argb alloc", e);
 	if ((e = t->counters.reserve(SRT_CTR_COUNT)) != hipSuccess) return bail("counter alloc", e);
-	if ((e = t->wave_counters.reserve((size_t)SRT_WAVE_CTR_SLOTS * SRT_WAVE_CTR_STRIDE)) != hipSuccess) return bail("counter alloc", e);
+	if ((e = t->wave_counters.reserve((size_t)2 * SRT_WAVE_CTR_SLOTS * SRT_WAVE_CTR_STRIDE)) != hipSuccess) return bail("counter alloc", e);
 	if ((e = t->shapes.reserve(1)) != hipSuccess || (e = t->runs.reserve(1)) != hipSuccess ||
 	    (e = t->run_data.reserve(32)) != hipSuccess || (e = t->winners.reserve(1)) != hipSuccess ||
 	    (e = t->triangles.reserve(1)) != hipSuccess || (e = t->materials.reserve(1)) != hipSuccess ||
@@ -465,7 +472,7 @@ int srt_create(int width, int height, int device_index, srt_tracer **out) {
 	    (e = hipEventCreate(&t->ev_r0)) != hipSuccess || (e = hipEventCreate(&t->ev_r1)) != hipSuccess)
 		return bail("hipEventCreate", e);
 	if ((e = hipMemsetAsync(t->canvas, 0, t->canvas_bytes, t->stream)) != hipSuccess) return bail("canvas clear", e);
-	if ((e = hipMemsetAsync(t->wave_counters.ptr, 0, (size_t)SRT_WAVE_CTR_SLOTS * SRT_WAVE_CTR_STRIDE * sizeof(unsigned long long), t->stream)) != hipSuccess)
+	if ((e = hipMemsetAsync(t->wave_counters.ptr, 0, (size_t)2 * SRT_WAVE_CTR_SLOTS * SRT_WAVE_CTR_STRIDE * sizeof(unsigned long long), t->stream)) != hipSuccess)
 		return bail("counter clear", e);
 	if ((e = hipMemsetAsync(t->counters.ptr, 0, SRT_CTR_COUNT * sizeof(unsigned long long), t->stream)) != hipSuccess)
 		return bail("counter clear", e);
@@ -502,6 +509,12 @@ void srt_destroy(srt_tracer *t) {
 	if (t->ev_r0) (void)hipEventDestroy(t->ev_r0);
 	if (t->ev_r1) (void)hipEventDestroy(t->ev_r1);
 	for (hipEvent_t ev : t->ev_k) (void)hipEventDestroy(ev);
+	for (int k = 0; k < 2; k++) {
+		if (t->ev_batch_traced[k]) (void)hipEventDestroy(t->ev_batch_traced[k]);
+		if (t->ev_batch_reduced[k]) (void)hipEventDestroy(t->ev_batch_reduced[k]);
+		if (t->batch_stream[k]) (void)hipStreamDestroy(t->batch_stream[k]);
+	}
+	if (t->ev_batch_fork) (void)hipEventDestroy(t->ev_batch_fork);
 	if (t->own_stream) (void)hipStreamDestroy(t->own_stream);
 	delete t->bvh_cache;
 	delete t;
@@ -877,19 +890,26 @@ int srt_trace(srt_tracer *t, const srt_render_data *options) {
 		if (fit32 < fit) fit = fit32 ? fit32 : 1;
 		if (fit < batch) batch = (uint32_t)fit;
 		// Array scan of large meshes: a ray that enters a model's box tests every triangle, so one launch over all samples
-		// can run for tens of seconds (BASELINE configs[4]: ~14 s) -- longer than a compute queue should be held. Sample
-		// batches bound a launch by 2e12 ray-triangle pairs if EVERY path entered every box (a few seconds at worst).
+		// can run for a long time (BASELINE configs[4]: 5.8 s; a denser mesh or more samples: minutes) -- longer than a
+		// compute queue should be held. Sample batches bound a launch by SRT_SCAN_PAIRS_PER_LAUNCH ray-triangle pairs counted
+		// as if EVERY path entered every box once (~1 s at the measured 9e12 such pairs per second; a launch whose paths all
+		// bounce ten times inside a box takes ten times that). A batch ends in a long tail -- the last rays scan a few lanes
+		// at a time -- which is why batches overlap (below) and are not made smaller than this: configs[4] at full size,
+		// batches of 8 / 16 / 32 samples one after the other 15.0 / - / 7.9 s, overlapped 8.5 / 6.8 / 6.4 s.
 		if (t->scan_tris > 4096) {
 			const double per_sample = (double)pixels * (double)t->scan_tris;
-			const double cap = 2e12 / per_sample;
+			const double cap = SRT_SCAN_PAIRS_PER_LAUNCH / per_sample;
 			const uint32_t cap_u = cap < 1.0 ? 1u : (cap > 1e9 ? 0xffffffffu : (uint32_t)cap);
 			if (cap_u < batch) batch = cap_u;
 		}
+		// several batches alternate between TWO radiance buffers (below): both must fit the budget
+		if (SRT_OVERLAP_BATCHES && batch < (uint32_t)ns && (size_t)batch * 2 > fit) batch = (uint32_t)(fit / 2 ? fit / 2 : 1);
 		if (batch > 4 && (batch & 3u)) batch &= ~3u; // keep the reduce kernel's 16-byte loads aligned
 	}
 	// allocate; if the device cannot give that much right now, fall back to smaller batches
 	while (batch) {
-		hipError_t e = t->radiance.reserve(pixels * (size_t)batch * 3 + 4);
+		const size_t buffers = SRT_OVERLAP_BATCHES && batch < (uint32_t)ns ? 2 : 1;
+		hipError_t e = t->radiance.reserve(buffers * (pixels * (size_t)batch * 3 + 4));
 		if (e == hipSuccess) break;
 		(void)hipGetLastError(); // clear the sticky out-of-memory state
 		if (e != hipErrorOutOfMemory || batch == 1)
@@ -936,7 +956,32 @@ int srt_trace(srt_tracer *t, const srt_render_data *options) {
 		rp.first_batch = rp.last_batch = 1;
 		srt_launch_reduce(rp, t->stream);
 	}
+	// Several sample batches: even and odd batches trace on two streams of their own, each into its own radiance buffer,
+	// work cursor and set of per-wave counter lines, so that the tail of a batch (its last long paths, a few lanes per wave
+	// and most waves gone: half of a launch of the 10^5-triangle array scan) runs under the next batch instead of leaving
+	// the GPU idle. The ordered reductions stay on the caller's stream, in batch order; a batch's trace waits for the
+	// reduction that last read its buffer.
+	const bool overlap = SRT_OVERLAP_BATCHES && n_batches > 1;
+	t->batches_overlapped = overlap;
+	const size_t radiance_stride = pixels * (size_t)batch * 3 + 4; // floats per buffer
+	if (overlap) {
+		for (int k = 0; k < 2; k++) {
+			if (!t->batch_stream[k]) SRT_HIP(t, hipStreamCreateWithFlags(&t->batch_stream[k], hipStreamNonBlocking));
+			if (!t->ev_batch_traced[k]) SRT_HIP(t, hipEventCreateWithFlags(&t->ev_batch_traced[k], hipEventDisableTiming));
+			if (!t->ev_batch_reduced[k]) SRT_HIP(t, hipEventCreateWithFlags(&t->ev_batch_reduced[k], hipEventDisableTiming));
+		}
+		if (!t->ev_batch_fork) SRT_HIP(t, hipEventCreateWithFlags(&t->ev_batch_fork, hipEventDisableTiming));
+		SRT_HIP(t, hipEventRecord(t->ev_batch_fork, t->stream)); // everything the caller's stream holds so far (scene upload, clear, ...)
+		for (int k = 0; k < 2; k++) SRT_HIP(t, hipStreamWaitEvent(t->batch_stream[k], t->ev_batch_fork, 0));
+	}
 	for (uint32_t b = 0; b < n_batches; b++) {
+		const int par = overlap ? (int)(b & 1u) : 0;
+		hipStream_t ts = overlap ? t->batch_stream[par] : t->stream;
+		p.radiance = t->radiance.ptr + (size_t)par * radiance_stride;
+		rp.radiance = p.radiance;
+		p.queue = t->counters.ptr + (par ? SRT_CTR_QUEUE2 : SRT_CTR_QUEUE);
+		p.wave_counters = t->wave_counters.ptr + (size_t)par * SRT_WAVE_CTR_SLOTS * SRT_WAVE_CTR_STRIDE;
+		if (overlap && b >= 2) SRT_HIP(t, hipStreamWaitEvent(ts, t->ev_batch_reduced[par], 0)); // batch b - 2 has been summed up
 		const uint32_t s0 = b * batch;
 		const uint32_t nbs = (uint32_t)ns - s0 < batch ? (uint32_t)ns - s0 : batch;
 		p.batch_samples = nbs;
@@ -961,18 +1006,23 @@ int srt_trace(srt_tracer *t, const srt_render_data *options) {
 		p.job_items = (uint32_t)job;
 		const unsigned long long waves_needed = (p.total_items + 63ull) / 64ull;
 		const int num_waves = (int)(waves_needed < slots_b ? waves_needed : slots_b);
-		SRT_HIP(t, hipMemsetAsync(p.queue, 0, sizeof(unsigned long long), t->stream));
-		SRT_HIP(t, hipEventRecord(t->ev_k[2 * b], t->stream));
+		SRT_HIP(t, hipMemsetAsync(p.queue, 0, sizeof(unsigned long long), ts));
+		SRT_HIP(t, hipEventRecord(t->ev_k[2 * b], ts));
 		t->last_grid = num_waves;
-		srt_launch_trace(p, t->count_tris, num_waves, t->stream);
+		srt_launch_trace(p, t->count_tris, num_waves, ts);
 		SRT_HIP(t, hipGetLastError());
-		SRT_HIP(t, hipEventRecord(t->ev_k[2 * b + 1], t->stream));
+		SRT_HIP(t, hipEventRecord(t->ev_k[2 * b + 1], ts));
+		if (overlap) {
+			SRT_HIP(t, hipEventRecord(t->ev_batch_traced[par], ts));
+			SRT_HIP(t, hipStreamWaitEvent(t->stream, t->ev_batch_traced[par], 0));
+		}
 		t->ev_k_used = 2 * (size_t)(b + 1);
 		rp.batch_samples = nbs;
 		rp.first_batch = (b == 0);
 		rp.last_batch = (b == n_batches - 1);
 		srt_launch_reduce(rp, t->stream);
 		SRT_HIP(t, hipGetLastError());
+		if (overlap) SRT_HIP(t, hipEventRecord(t->ev_batch_reduced[par], t->stream));
 	}
 	SRT_HIP(t, hipEventRecord(t->ev_t1, t->stream));
 	t->have_trace_ev = true;
@@ -1070,7 +1120,7 @@ int srt_get_counters(srt_tracer *t, srt_counters *out) {
 	unsigned long long h[SRT_CTR_COUNT];
 	std::vector<unsigned long long> w;
 	try {
-		w.resize((size_t)SRT_WAVE_CTR_SLOTS * SRT_WAVE_CTR_STRIDE);
+		w.resize((size_t)2 * SRT_WAVE_CTR_SLOTS * SRT_WAVE_CTR_STRIDE);
 	} catch (...) {
 		return fail(t, SRT_ERR_INVALID, "out of host memory");
 	}
@@ -1078,7 +1128,7 @@ int srt_get_counters(srt_tracer *t, srt_counters *out) {
 	SRT_HIP(t, hipMemcpyAsync(w.data(), t->wave_counters.ptr, w.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, t->stream));
 	SRT_HIP(t, hipStreamSynchronize(t->stream));
 	unsigned long long sum[5] = {0, 0, 0, 0, 0};
-	for (size_t i = 0; i < (size_t)SRT_WAVE_CTR_SLOTS; i++)
+	for (size_t i = 0; i < (size_t)2 * SRT_WAVE_CTR_SLOTS; i++)
 		for (int k = 0; k < 5; k++) sum[k] += w[i * SRT_WAVE_CTR_STRIDE + k];
 	out->rays = sum[0];
 	out->sky = sum[1];
@@ -1094,7 +1144,7 @@ int srt_reset_counters(srt_tracer *t) {
 	if (!t) return SRT_ERR_INVALID;
 	SRT_HIP(t, hipSetDevice(t->device));
 	SRT_HIP(t, hipMemsetAsync(t->counters.ptr, 0, SRT_CTR_COUNT * sizeof(unsigned long long), t->stream));
-	SRT_HIP(t, hipMemsetAsync(t->wave_counters.ptr, 0, (size_t)SRT_WAVE_CTR_SLOTS * SRT_WAVE_CTR_STRIDE * sizeof(unsigned long long), t->stream));
+	SRT_HIP(t, hipMemsetAsync(t->wave_counters.ptr, 0, (size_t)2 * SRT_WAVE_CTR_SLOTS * SRT_WAVE_CTR_STRIDE * sizeof(unsigned long long), t->stream));
 	return SRT_OK;
 }
 
@@ -1125,12 +1175,21 @@ int srt_last_trace_kernel_ms(srt_tracer *t, float *kernel_ms) {
 	SRT_HIP(t, hipSetDevice(t->device));
 	SRT_HIP(t, hipStreamSynchronize(t->stream));
 	*kernel_ms = 0.f;
-	if (t->have_kernel_ev)
+	if (t->have_kernel_ev && t->batches_overlapped && t->ev_k_used >= 4) {
+		// overlapping launches: from the first batch's start to the later of the last two ends (the reductions of the earlier
+		// batches run inside that span)
+		for (size_t i = t->ev_k_used - 4; i + 1 < t->ev_k_used; i += 2) {
+			float ms = 0.f;
+			SRT_HIP(t, hipEventElapsedTime(&ms, t->ev_k[0], t->ev_k[i + 1]));
+			if (ms > *kernel_ms) *kernel_ms = ms;
+		}
+	} else if (t->have_kernel_ev) {
 		for (size_t i = 0; i + 1 < t->ev_k_used; i += 2) { // one pair per sample batch: the reductions between them are not counted
 			float ms = 0.f;
 			SRT_HIP(t, hipEventElapsedTime(&ms, t->ev_k[i], t->ev_k[i + 1]));
 			*kernel_ms += ms;
 		}
+	}
 	return SRT_OK;
 }
 
@@ -1273,14 +1332,14 @@ int srt_debug_counters(srt_tracer *t, uint64_t out[18]) {
 	SRT_HIP(t, hipSetDevice(t->device));
 	std::vector<unsigned long long> w;
 	try {
-		w.resize((size_t)SRT_WAVE_CTR_SLOTS * SRT_WAVE_CTR_STRIDE);
+		w.resize((size_t)2 * SRT_WAVE_CTR_SLOTS * SRT_WAVE_CTR_STRIDE);
 	} catch (...) {
 		return fail(t, SRT_ERR_INVALID, "out of host memory");
 	}
 	SRT_HIP(t, hipMemcpyAsync(w.data(), t->wave_counters.ptr, w.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, t->stream));
 	SRT_HIP(t, hipStreamSynchronize(t->stream));
 	for (int k = 0; k < 18; k++) out[k] = 0;
-	for (size_t i = 0; i < (size_t)SRT_WAVE_CTR_SLOTS; i++) {
+	for (size_t i = 0; i < (size_t)2 * SRT_WAVE_CTR_SLOTS; i++) {
 		for (int k = 0; k < 8; k++) out[k] += w[i * SRT_WAVE_CTR_STRIDE + k];
 		for (int k = 8; k < 16; k++) out[k + 2] += w[i * SRT_WAVE_CTR_STRIDE + k]; // phase clocks of -DSRT_PHASE_CLOCK builds
 	}

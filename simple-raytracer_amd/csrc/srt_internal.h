@@ -69,6 +69,11 @@ struct srt_tracer {
 	int num_cus = 0;
 	int last_waves_per_cu = 0, last_grid = 0;
 	std::vector<hipEvent_t> ev_k; // one pair per sample batch, around srt_trace_kernel alone (reduce excluded)
+	// dispatches of several sample batches: even / odd batches trace on two streams of their own so that one batch's tail
+	// (its last long paths, a few lanes per wave) runs under the next batch's start; the reductions stay in order on `stream`
+	hipStream_t batch_stream[2] = {nullptr, nullptr};
+	hipEvent_t ev_batch_traced[2] = {nullptr, nullptr}, ev_batch_reduced[2] = {nullptr, nullptr}, ev_batch_fork = nullptr;
+	bool batches_overlapped = false; // the last srt_trace ran that way (srt_last_trace_kernel_ms: a span, not a sum)
 	size_t ev_k_used = 0;         // events of the last srt_trace
 	float last_trace_kernel_ms = 0.f, last_reduce_ms = 0.f;
 	int sky_w = 0, sky_h = 0;

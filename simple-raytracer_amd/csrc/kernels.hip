@@ -1254,7 +1254,11 @@ __global__ __launch_bounds__(64, USE_BVH ? SRT_TRACE_WAVES_PER_SIMD_BVH : HAS_MO
 						unsigned long long start = total_items;
 						if (own_chunks_end < (unsigned long long)total_items) { // else every chunk is some wave's first: nothing to ask the cursor for
 							if (lane == 0) start = atomicAdd(p.queue, (unsigned long long)p.job_items);
-							start = (unsigned long long)__shfl((long long)start, 0) + own_chunks_end;
+							// lane 0's value as a scalar (wave-uniform control flow: lane 0 is active), so that everything derived from
+							// it -- chunk bounds, sub-job bases -- stays in SGPRs
+							const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)start);
+							const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(start >> 32));
+							start = (((unsigned long long)hi << 32) | lo) + own_chunks_end;
 						}
 						if (start >= (unsigned long long)total_items) {
 							queue_dry = true;

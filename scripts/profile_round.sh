@@ -27,6 +27,6 @@ PY
 python bench.py --workload meshes_1080p_512spp --steps 3 --no-cpu-baseline > $OUT/bench_meshes_scan.json 2>/dev/null; echo "meshes scan rc=$?"
 python bench.py --workload meshes_1080p_512spp --accel bvh --steps 3 --no-cpu-baseline > $OUT/bench_meshes_bvh.json 2>/dev/null; echo "meshes bvh rc=$?"
 python bench.py --workload mesh100k_1080p_256spp --accel bvh --steps 3 --no-cpu-baseline > $OUT/bench_mesh100k_bvh.json 2>/dev/null; echo "mesh100k bvh rc=$?"
-python bench.py --workload spheres_4k_4096spp --steps 1 --warmup 0 --no-cpu-baseline > $OUT/bench_4k_1gpu.json 2>/dev/null; echo "4k rc=$?"
+python bench.py --workload spheres_4k_4096spp --steps 1 --warmup 1 --no-cpu-baseline > $OUT/bench_4k_1gpu.json 2>/dev/null; echo "4k rc=$?"
 python bench.py --workload spheres_256_16spp --steps 20 --warmup 2 > $OUT/bench_config0.json 2>/dev/null; echo "config0 rc=$?"
 for f in $OUT/bench*.json; do echo "$(basename $f): $(python3 -c "import json,sys; d=json.load(open('$f')); print(d['value'], d['unit'], d['ms_per_step'], 'ms', d['roofline']['frac'])")"; done

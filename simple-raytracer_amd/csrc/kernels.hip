@@ -155,6 +155,12 @@ __device__ __forceinline__ f3 mat_by_vec(const srt_float4 *m, f3 v, float w) {
 	          ((m[0].z * v.x + m[1].z * v.y) + m[2].z * v.z) + m[3].z * w);
 }
 
+// the same, the matrix given by its columns' x, y, z
+__device__ __forceinline__ f3 mat_cols_by_vec(f3 c0, f3 c1, f3 c2, f3 c3, f3 v, float w) {
+	return mk(((c0.x * v.x + c1.x * v.y) + c2.x * v.z) + c3.x * w, ((c0.y * v.x + c1.y * v.y) + c2.y * v.z) + c3.y * w,
+	          ((c0.z * v.x + c1.z * v.y) + c2.z * v.z) + c3.z * w);
+}
+
 // v - 2 (v.n) n  (render.cl:139-141)
 __device__ __forceinline__ f3 reflect3(f3 v, f3 n) { return v - n * (2.0f * dot3(v, n)); }
 
@@ -581,9 +587,25 @@ __device__ __forceinline__ f3 sample_sky(const float *__restrict__ sky, int W, i
 	          dm_bilinear(w00, T00.z, w10, T10.z, w01, T01.z, w11, T11.z));
 }
 
+// The launch parameters as they lie in the kernel-argument segment, behind a pointer the compiler cannot see through: what
+// is read through it is loaded (scalar loads, scalar-cache hits) where it is used instead of living in SGPRs for the whole
+// launch. The persistent loop has far more wave-uniform state than SGPRs; parameters only the sky and the camera rays need
+// (sun, image size, camera matrix: ~45 dwords) were being spilled to VGPR lanes and read back with a v_readlane each.
+#ifndef SRT_COLD_PARAMS_LIVE
+__device__ __forceinline__ const SRT_AS_CONST TraceParams *cold_params() {
+	const SRT_AS_CONST TraceParams *kp = (const SRT_AS_CONST TraceParams *)__builtin_amdgcn_kernarg_segment_ptr();
+	asm volatile("" : "+s"(kp));
+	return kp;
+}
+#define SRT_COLD(p) (*cold_params())
+#else
+#define SRT_COLD(p) (p)
+#endif
+
 // render.cl:380-394
-__device__ __forceinline__ f3 sky_box(const TraceParams &p, f3 dir) {
-	f3 sun_dir = ld3(p.sd.sun_direction);
+__device__ __forceinline__ f3 sky_box(const TraceParams &p_live, f3 dir) {
+	const auto &p = SRT_COLD(p_live);
+	f3 sun_dir = mk(p.sd.sun_direction.x, p.sd.sun_direction.y, p.sd.sun_direction.z);
 	// dm_powf(x, sun_focus) with its (wave-uniform) choice of path made once on the host
 	const float lobe_x = dm_max(dot3(dir, neg(sun_dir)), 0.0f);
 	float lobe;
@@ -592,10 +614,10 @@ __device__ __forceinline__ f3 sky_box(const TraceParams &p, f3 dir) {
 	} else {
 		lobe = dm_powf(lobe_x, p.sd.sun_focus);
 	}
-	f3 sun = (ld3(p.sd.sun_color) * lobe) * p.sd.sun_intensity;
+	f3 sun = (mk(p.sd.sun_color.x, p.sd.sun_color.y, p.sd.sun_color.z) * lobe) * p.sd.sun_intensity;
 	float u = dm_atan2pif(dir.z, dir.x) * 0.5f + 0.5f;
 	float v = dir.y * 0.5f + 0.5f;
-	return sample_sky(p.sky, p.sky_w, p.sky_h, p.f_sky_w, p.f_sky_h, u, v) + sun;
+	return sample_sky((const float *)p.sky, p.sky_w, p.sky_h, p.f_sky_w, p.f_sky_h, u, v) + sun;
 }
 
 
@@ -1253,7 +1275,7 @@ __global__ __launch_bounds__(64, USE_BVH ? SRT_TRACE_WAVES_PER_SIMD_BVH : HAS_MO
 					if (chunk_cur == chunk_end) {
 						unsigned long long start = total_items;
 						if (own_chunks_end < (unsigned long long)total_items) { // else every chunk is some wave's first: nothing to ask the cursor for
-							if (lane == 0) start = atomicAdd(p.queue, (unsigned long long)p.job_items);
+							if (lane == 0) start = atomicAdd((unsigned long long *)SRT_COLD(p).queue, (unsigned long long)SRT_COLD(p).job_items);
 							// lane 0's value as a scalar (wave-uniform control flow: lane 0 is active), so that everything derived from
 							// it -- chunk bounds, sub-job bases -- stays in SGPRs
 							const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)start);
@@ -1265,7 +1287,8 @@ __global__ __launch_bounds__(64, USE_BVH ? SRT_TRACE_WAVES_PER_SIMD_BVH : HAS_MO
 							break;
 						}
 						chunk_cur = (uint32_t)start;
-						chunk_end = (total_items - chunk_cur < p.job_items) ? total_items : chunk_cur + p.job_items;
+						const uint32_t job_items = SRT_COLD(p).job_items;
+						chunk_end = (total_items - chunk_cur < job_items) ? total_items : chunk_cur + job_items;
 					}
 					const uint32_t left = chunk_end - chunk_cur;
 					const uint32_t n = left < SUB ? left : SUB;
@@ -1295,20 +1318,24 @@ __global__ __launch_bounds__(64, USE_BVH ? SRT_TRACE_WAVES_PER_SIMD_BVH : HAS_MO
 			}
 			if (got) {
 				// ---- camera ray (render.cl:488,496-516) ----
+				const auto &c = SRT_COLD(p);
 				const uint32_t dq = (nbs >= SUB) ? (off >= nbs ? 1u : 0u) : off / nbs;
 				const uint32_t q = qpix + dq; // owned pixels < 2^31 (checked by the host)
-				const uint32_t sample = p.first_sample + (off - dq * nbs);
+				const uint32_t sample = c.first_sample + (off - dq * nbs);
 				const uint32_t lrow = q / (uint32_t)width;
 				const int px = (int)(q - lrow * (uint32_t)width);
-				const int py = p.world == 1 ? (int)lrow : global_row((int)lrow, p.rank, p.world, p.rows_per_block); // (wave-uniform choice)
+				const int py = c.world == 1 ? (int)lrow : global_row((int)lrow, c.rank, c.world, c.rows_per_block); // (wave-uniform choice)
 				const uint32_t id = (uint32_t)px + (uint32_t)py * (uint32_t)width;
-				seed = (sample + id * (uint32_t)ns) * p.rd.time * 5304u;
-				float ndc_x = ((float)px + random_float(seed)) / p.f_width;
-				float ndc_y = ((float)py + random_float(seed)) / p.f_height;
-				float sx = ((2.f * ndc_x - 1.f) * p.rd.aspect_ratio) * p.rd.fov_scale;
-				float sy = (1.f - 2.f * ndc_y) * p.rd.fov_scale;
-				dir = normalize3(mat_by_vec(p.rd.camera_to_world, mk(sx, sy, -1.0f), 0.0f));
-				org = mk(p.rd.camera_to_world[3].x, p.rd.camera_to_world[3].y, p.rd.camera_to_world[3].z);
+				seed = (sample + id * (uint32_t)ns) * c.rd.time * 5304u;
+				float ndc_x = ((float)px + random_float(seed)) / c.f_width;
+				float ndc_y = ((float)py + random_float(seed)) / c.f_height;
+				float sx = ((2.f * ndc_x - 1.f) * c.rd.aspect_ratio) * c.rd.fov_scale;
+				float sy = (1.f - 2.f * ndc_y) * c.rd.fov_scale;
+				const f3 c0 = mk(c.rd.camera_to_world[0].x, c.rd.camera_to_world[0].y, c.rd.camera_to_world[0].z);
+				const f3 c1 = mk(c.rd.camera_to_world[1].x, c.rd.camera_to_world[1].y, c.rd.camera_to_world[1].z);
+				const f3 c2 = mk(c.rd.camera_to_world[2].x, c.rd.camera_to_world[2].y, c.rd.camera_to_world[2].z);
+				org = mk(c.rd.camera_to_world[3].x, c.rd.camera_to_world[3].y, c.rd.camera_to_world[3].z);
+				dir = normalize3(mat_cols_by_vec(c0, c1, c2, org, mk(sx, sy, -1.0f), 0.0f)); // (the position column times w = 0 stays: inf * 0 is a NaN the reference has, too)
 				mask = mk(1.f, 1.f, 1.f);
 				color = mk(0.f, 0.f, 0.f);
 				bounce = 0;
@@ -1321,7 +1348,7 @@ __global__ __launch_bounds__(64, USE_BVH ? SRT_TRACE_WAVES_PER_SIMD_BVH : HAS_MO
 			if (queue_dry) break;
 			// Bounded: a wave that spins here without ever getting work leaves with the watchdog counter set instead of hanging.
 			if (++idle_spins > (1u << 20)) {
-				if (lane == 0) atomicAdd(&p.counters[SRT_CTR_WATCHDOG], 1ull);
+				if (lane == 0) atomicAdd((unsigned long long *)SRT_COLD(p).counters + SRT_CTR_WATCHDOG, 1ull);
 				break;
 			}
 		} else {
@@ -1342,7 +1369,7 @@ __global__ __launch_bounds__(64, USE_BVH ? SRT_TRACE_WAVES_PER_SIMD_BVH : HAS_MO
 		}
 	}
 	if (lane == 0) {
-		unsigned long long *__restrict__ w = p.wave_counters + (size_t)blockIdx.x * SRT_WAVE_CTR_STRIDE;
+		unsigned long long *__restrict__ w = (unsigned long long *)SRT_COLD(p).wave_counters + (size_t)blockIdx.x * SRT_WAVE_CTR_STRIDE;
 		w[0] += w_rays;
 		w[1] += w_sky;
 		w[2] += w_paths;

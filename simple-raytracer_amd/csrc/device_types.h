@@ -117,6 +117,7 @@ struct TraceParams {
 	int32_t rank, world, rows_per_block, owned_rows;
 	int32_t use_bvh;          /* model records carry a BVH root instead of a first world triangle */
 	const float *bvh_blocks;  /* all models' 128-byte blocks (wide hierarchy above) */
+	float *scan_queue;        /* array scan: 19 x 64 floats per persistent wave (rays that wait for a big model's triangle scan) */
 };
 
 struct PrepassParams {
@@ -157,6 +158,8 @@ int srt_trace_waves_per_simd(int has_models, int use_bvh);
 int srt_trace_resident_waves_per_cu(const TraceParams &p, bool count_triangles); /* from the runtime's occupancy calculator */
 int srt_scan_suspend_min(void); /* array scan: models of at least this many triangles sit alone in their block and are flagged big */
 int srt_sub_job_items(int has_models, int use_bvh); /* items per LDS-staged sub-job; chunks per atomic are multiples of it */
+int srt_scan_queue_in_hbm(void); /* 1: TraceParams.scan_queue must point at SRT_SCAN_QUEUE_FLOATS floats per wave of the launch */
+#define SRT_SCAN_QUEUE_FLOATS (19 * 64)
 void srt_launch_prepass(const PrepassParams &p, uint64_t total_wtris, void *stream);
 void srt_launch_resolve(const ResolveParams &p, void *stream);
 void srt_launch_selftest(unsigned long long *out12, uint32_t stride, void *stream);

@@ -774,8 +774,11 @@ __device__ __forceinline__ void resolve_ring(const TraceParams &p, const float *
 #ifndef SRT_TRACE_WAVES_PER_SIMD
 #define SRT_TRACE_WAVES_PER_SIMD 5
 #endif
+#ifndef SRT_SQ_GLOBAL
+#define SRT_SQ_GLOBAL 1 // array-scan kernels: the scan queue in HBM (0: in LDS, 13 instead of 20 waves per CU)
+#endif
 #ifndef SRT_TRACE_WAVES_PER_SIMD_MODELS
-#define SRT_TRACE_WAVES_PER_SIMD_MODELS 4
+#define SRT_TRACE_WAVES_PER_SIMD_MODELS (SRT_SQ_GLOBAL ? 5 : 4)
 #endif
 #ifndef SRT_TRACE_WAVES_PER_SIMD_BVH
 #define SRT_TRACE_WAVES_PER_SIMD_BVH 4
@@ -840,7 +843,16 @@ __global__ __launch_bounds__(64, USE_BVH ? SRT_TRACE_WAVES_PER_SIMD_BVH : HAS_MO
 	// array-scan kernels: rays waiting for the triangle scan of a big model (stack of 64 records x 19 fields)
 	constexpr bool SUSPEND = HAS_MODELS && !USE_BVH;
 	constexpr uint32_t SQ = 64u;
+#if SRT_SQ_GLOBAL
+	// The scan queue lives in HBM, one 19 x 64 record block per persistent wave: in LDS it cost the array-scan kernels
+	// a third of their waves (11.7 KB per wave: 13 per CU; without it 6.8 KB and the register file's 20). A record is
+	// written and read once per triangle scan of at least 128 triangles -- microseconds of memory latency against tens of
+	// microseconds of scanning. Stores are plain (write-through), loads bypass the vector L1 (a slot is reused, and the L1
+	// keeps no track of this CU's own stores) and wait for the wave's stores first (pop below).
+	float *__restrict__ sq = SUSPEND ? const_cast<float *>((const float *)SRT_COLD(p).scan_queue) + (size_t)blockIdx.x * (19u * SQ) : nullptr;
+#else
 	float *__restrict__ sq = hq + (HAS_MODELS ? (USE_BVH ? 18u : 17u) : 16u) * HQ;
+#endif
 	uint32_t sq_count = 0; // wave-uniform
 	uint32_t ring_count = 0, hq_head = 0, hq_count = 0;                        // wave-uniform
 
@@ -1231,18 +1243,23 @@ __global__ __launch_bounds__(64, USE_BVH ? SRT_TRACE_WAVES_PER_SIMD_BVH : HAS_MO
 		if (SUSPEND && sq_count != 0u && n_free != 0u &&
 		    (queue_dry || (n_free >= (uint32_t)SRT_REFILL_MIN && sq_count >= (n_free < (uint32_t)SRT_SCAN_NOW_MIN ? n_free : (uint32_t)SRT_SCAN_NOW_MIN)))) {
 			// rays that wait for a big model's triangle scan come first: together they fill the wave for it
-			asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+			asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); // the records' stores have arrived (LDS, or HBM: acknowledged by the L2)
 			const uint32_t n_pop = n_free < sq_count ? n_free : sq_count;
 			const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(freeb >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)freeb, 0u));
 			if (!active && rank < n_pop) {
 				const uint32_t e = sq_count - 1u - rank;
-				org = mk(sq[0 * SQ + e], sq[1 * SQ + e], sq[2 * SQ + e]);
-				dir = mk(sq[3 * SQ + e], sq[4 * SQ + e], sq[5 * SQ + e]);
-				mask = mk(sq[6 * SQ + e], sq[7 * SQ + e], sq[8 * SQ + e]);
-				color = mk(sq[9 * SQ + e], sq[10 * SQ + e], sq[11 * SQ + e]);
-				seed = dm_f2u(sq[12 * SQ + e]), bounce = (int)dm_f2u(sq[13 * SQ + e]), item = dm_f2u(sq[14 * SQ + e]);
-				tmin = sq[15 * SQ + e], best = (int)dm_f2u(sq[16 * SQ + e]), best_tri = dm_f2u(sq[17 * SQ + e]);
-				pos = dm_f2u(sq[18 * SQ + e]);
+#if SRT_SQ_GLOBAL
+				auto rd = [&](uint32_t k) { return dm_u2f(__hip_atomic_load(reinterpret_cast<const uint32_t *>(sq) + k * SQ + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)); };
+#else
+				auto rd = [&](uint32_t k) { return sq[k * SQ + e]; };
+#endif
+				org = mk(rd(0), rd(1), rd(2));
+				dir = mk(rd(3), rd(4), rd(5));
+				mask = mk(rd(6), rd(7), rd(8));
+				color = mk(rd(9), rd(10), rd(11));
+				seed = dm_f2u(rd(12)), bounce = (int)dm_f2u(rd(13)), item = dm_f2u(rd(14));
+				tmin = rd(15), best = (int)dm_f2u(rd(16)), best_tri = dm_f2u(rd(17));
+				pos = dm_f2u(rd(18));
 				resumed = true;
 				active = true;
 			}
@@ -1602,12 +1619,13 @@ int srt_trace_waves_per_simd(int has_models, int use_bvh) {
 	return !has_models ? SRT_TRACE_WAVES_PER_SIMD : use_bvh ? SRT_TRACE_WAVES_PER_SIMD_BVH : SRT_TRACE_WAVES_PER_SIMD_MODELS;
 }
 int srt_scan_suspend_min(void) { return SRT_SCAN_SUSPEND_MIN; }
+int srt_scan_queue_in_hbm(void) { return SRT_SQ_GLOBAL; }
 int srt_sub_job_items(int has_models, int use_bvh) { return !has_models ? SRT_SUB_PLAIN : use_bvh ? SRT_SUB_BVH : SRT_SUB_MODELS; }
 
 int srt_trace_lds_floats(int has_models, int use_bvh) {
 	// two staging buffers of packed 12-byte items, the sky ring (10 fields), the hit queue (16..18 fields)
 	const int sub = srt_sub_job_items(has_models, use_bvh);
-	return 2 * sub * 3 + 10 * SRT_RING_CAP + (has_models ? (use_bvh ? 18 * SRT_HQ_CAP_BVH : 17 * SRT_HQ_CAP) : 16 * SRT_HQ_CAP) + (has_models && !use_bvh ? 19 * 64 : 0);
+	return 2 * sub * 3 + 10 * SRT_RING_CAP + (has_models ? (use_bvh ? 18 * SRT_HQ_CAP_BVH : 17 * SRT_HQ_CAP) : 16 * SRT_HQ_CAP) + (has_models && !use_bvh && !SRT_SQ_GLOBAL ? 19 * 64 : 0);
 }
 
 namespace {

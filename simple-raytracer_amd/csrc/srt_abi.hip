@@ -502,6 +502,7 @@ void srt_destroy(srt_tracer *t) {
 	t->sky.release();
 	t->counters.release();
 	t->wave_counters.release();
+	t->scan_queue.release();
 	t->radiance.release();
 	t->running.release();
 	if (t->ev_t0) (void)hipEventDestroy(t->ev_t0);
@@ -930,6 +931,9 @@ int srt_trace(srt_tracer *t, const srt_render_data *options) {
 	int slots = t->num_cus * per_cu;
 	if (slots > SRT_WAVE_CTR_SLOTS) slots = SRT_WAVE_CTR_SLOTS; // one counter line per persistent wave
 
+	if (t->num_models > 0 && !t->bvh_active && srt_scan_queue_in_hbm()) // one block per persistent wave, two sets (overlapping batches)
+		SRT_HIP(t, t->scan_queue.reserve((size_t)2 * SRT_WAVE_CTR_SLOTS * SRT_SCAN_QUEUE_FLOATS));
+
 	ReduceParams rp;
 	rp.radiance = t->radiance.ptr;
 	rp.running = t->running.ptr;
@@ -981,6 +985,7 @@ int srt_trace(srt_tracer *t, const srt_render_data *options) {
 		rp.radiance = p.radiance;
 		p.queue = t->counters.ptr + (par ? SRT_CTR_QUEUE2 : SRT_CTR_QUEUE);
 		p.wave_counters = t->wave_counters.ptr + (size_t)par * SRT_WAVE_CTR_SLOTS * SRT_WAVE_CTR_STRIDE;
+		p.scan_queue = t->scan_queue.ptr ? t->scan_queue.ptr + (size_t)par * SRT_WAVE_CTR_SLOTS * SRT_SCAN_QUEUE_FLOATS : nullptr;
 		if (overlap && b >= 2) SRT_HIP(t, hipStreamWaitEvent(ts, t->ev_batch_reduced[par], 0)); // batch b - 2 has been summed up
 		const uint32_t s0 = b * batch;
 		const uint32_t nbs = (uint32_t)ns - s0 < batch ? (uint32_t)ns - s0 : batch;

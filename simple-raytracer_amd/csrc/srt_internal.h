@@ -63,6 +63,7 @@ struct srt_tracer {
 	struct BvhCache *bvh_cache = nullptr; // hierarchies of the previous srt_update_scene (see BvhCacheEntry)
 	DevBuf<unsigned long long> counters;
 	DevBuf<unsigned long long> wave_counters; // per persistent wave, summed in srt_get_counters
+	DevBuf<float> scan_queue;                 // array scan: per persistent wave (two sets, as the counters), allocated when first needed
 	DevBuf<float> radiance;  // 3 floats per (pixel, sample) of the current batch
 	DevBuf<float> running;   // float4 per pixel, carries the ordered sum across batches
 	size_t radiance_budget = 0; // bytes; 0 = pick from free HBM at first use

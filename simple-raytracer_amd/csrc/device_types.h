@@ -159,7 +159,10 @@ int srt_trace_resident_waves_per_cu(const TraceParams &p, bool count_triangles);
 int srt_scan_suspend_min(void); /* array scan: models of at least this many triangles sit alone in their block and are flagged big */
 int srt_sub_job_items(int has_models, int use_bvh); /* items per LDS-staged sub-job; chunks per atomic are multiples of it */
 int srt_scan_queue_in_hbm(void); /* 1: TraceParams.scan_queue must point at SRT_SCAN_QUEUE_FLOATS floats per wave of the launch */
-#define SRT_SCAN_QUEUE_FLOATS (19 * 64)
+#ifndef SRT_SQ_CAP
+#define SRT_SQ_CAP 64
+#endif
+#define SRT_SCAN_QUEUE_FLOATS (19 * SRT_SQ_CAP)
 void srt_launch_prepass(const PrepassParams &p, uint64_t total_wtris, void *stream);
 void srt_launch_resolve(const ResolveParams &p, void *stream);
 void srt_launch_selftest(unsigned long long *out12, uint32_t stride, void *stream);

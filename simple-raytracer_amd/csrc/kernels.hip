@@ -774,6 +774,9 @@ __device__ __forceinline__ void resolve_ring(const TraceParams &p, const float *
 #ifndef SRT_TRACE_WAVES_PER_SIMD
 #define SRT_TRACE_WAVES_PER_SIMD 5
 #endif
+#ifndef SRT_SQ_CAP
+#define SRT_SQ_CAP 64 // records of the scan queue when it lives in HBM (device_types.h SRT_SCAN_QUEUE_FLOATS follows)
+#endif
 #ifndef SRT_SQ_GLOBAL
 #define SRT_SQ_GLOBAL 1 // array-scan kernels: the scan queue in HBM (0: in LDS, 13 instead of 20 waves per CU)
 #endif
@@ -842,7 +845,7 @@ __global__ __launch_bounds__(64, USE_BVH ? SRT_TRACE_WAVES_PER_SIMD_BVH : HAS_MO
 	constexpr uint32_t HQ = USE_BVH ? SRT_HQ_CAP_BVH : SRT_HQ_CAP;
 	// array-scan kernels: rays waiting for the triangle scan of a big model (stack of 64 records x 19 fields)
 	constexpr bool SUSPEND = HAS_MODELS && !USE_BVH;
-	constexpr uint32_t SQ = 64u;
+	constexpr uint32_t SQ = SRT_SQ_GLOBAL ? (uint32_t)SRT_SQ_CAP : 64u;
 #if SRT_SQ_GLOBAL
 	// The scan queue lives in HBM, one 19 x 64 record block per persistent wave: in LDS it cost the array-scan kernels
 	// a third of their waves (11.7 KB per wave: 13 per CU; without it 6.8 KB and the register file's 20). A record is

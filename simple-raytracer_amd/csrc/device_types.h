@@ -162,7 +162,8 @@ int srt_scan_queue_in_hbm(void); /* 1: TraceParams.scan_queue must point at SRT_
 #ifndef SRT_SQ_CAP
 #define SRT_SQ_CAP 64
 #endif
-#define SRT_SCAN_QUEUE_FLOATS (19 * SRT_SQ_CAP)
+#define SRT_SCAN_QUEUE_FLOATS (20 * SRT_SQ_CAP)
+int srt_bvh_suspends(void);
 void srt_launch_prepass(const PrepassParams &p, uint64_t total_wtris, void *stream);
 void srt_launch_resolve(const ResolveParams &p, void *stream);
 void srt_launch_selftest(unsigned long long *out12, uint32_t stride, void *stream);

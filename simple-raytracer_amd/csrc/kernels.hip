@@ -774,6 +774,9 @@ __device__ __forceinline__ void resolve_ring(const TraceParams &p, const float *
 #ifndef SRT_TRACE_WAVES_PER_SIMD
 #define SRT_TRACE_WAVES_PER_SIMD 5
 #endif
+#ifndef SRT_BVH_SUSPEND
+#define SRT_BVH_SUSPEND 0 // BVH kernels gather the rays that enter a big model's box before they walk, as the array scan does
+#endif
 #ifndef SRT_SQ_CAP
 #define SRT_SQ_CAP 64 // records of the scan queue when it lives in HBM (device_types.h SRT_SCAN_QUEUE_FLOATS follows)
 #endif
@@ -844,7 +847,7 @@ __global__ __launch_bounds__(64, USE_BVH ? SRT_TRACE_WAVES_PER_SIMD_BVH : HAS_MO
 	float *__restrict__ hq = ring + 10u * (uint32_t)SRT_RING_CAP;                                 // [16..18][HQ] paths that hit, awaiting their bounce (FIFO)
 	constexpr uint32_t HQ = USE_BVH ? SRT_HQ_CAP_BVH : SRT_HQ_CAP;
 	// array-scan kernels: rays waiting for the triangle scan of a big model (stack of 64 records x 19 fields)
-	constexpr bool SUSPEND = HAS_MODELS && !USE_BVH;
+	constexpr bool SUSPEND = HAS_MODELS && (!USE_BVH || SRT_BVH_SUSPEND);
 	constexpr uint32_t SQ = SRT_SQ_GLOBAL ? (uint32_t)SRT_SQ_CAP : 64u;
 #if SRT_SQ_GLOBAL
 	// The scan queue lives in HBM, one 19 x 64 record block per persistent wave: in LDS it cost the array-scan kernels
@@ -852,7 +855,7 @@ __global__ __launch_bounds__(64, USE_BVH ? SRT_TRACE_WAVES_PER_SIMD_BVH : HAS_MO
 	// written and read once per triangle scan of at least 128 triangles -- microseconds of memory latency against tens of
 	// microseconds of scanning. Stores are plain (write-through), loads bypass the vector L1 (a slot is reused, and the L1
 	// keeps no track of this CU's own stores) and wait for the wave's stores first (pop below).
-	float *__restrict__ sq = SUSPEND ? const_cast<float *>((const float *)SRT_COLD(p).scan_queue) + (size_t)blockIdx.x * (19u * SQ) : nullptr;
+	float *__restrict__ sq = SUSPEND ? const_cast<float *>((const float *)SRT_COLD(p).scan_queue) + (size_t)blockIdx.x * (20u * SQ) : nullptr;
 #else
 	float *__restrict__ sq = hq + (HAS_MODELS ? (USE_BVH ? 18u : 17u) : 16u) * HQ;
 #endif
@@ -941,6 +944,7 @@ __global__ __launch_bounds__(64, USE_BVH ? SRT_TRACE_WAVES_PER_SIMD_BVH : HAS_MO
 										sq[12 * SQ + e] = dm_u2f(seed), sq[13 * SQ + e] = dm_u2f((uint32_t)bounce), sq[14 * SQ + e] = dm_u2f(item);
 										sq[15 * SQ + e] = tmin, sq[16 * SQ + e] = dm_u2f((uint32_t)best), sq[17 * SQ + e] = dm_u2f(best_tri);
 										sq[18 * SQ + e] = dm_u2f(bidx);
+										if (USE_BVH) sq[19 * SQ + e] = dm_u2f(best_j);
 										part = false;
 										suspended = true;
 									}
@@ -1263,6 +1267,7 @@ __global__ __launch_bounds__(64, USE_BVH ? SRT_TRACE_WAVES_PER_SIMD_BVH : HAS_MO
 				seed = dm_f2u(rd(12)), bounce = (int)dm_f2u(rd(13)), item = dm_f2u(rd(14));
 				tmin = rd(15), best = (int)dm_f2u(rd(16)), best_tri = dm_f2u(rd(17));
 				pos = dm_f2u(rd(18));
+				if (USE_BVH) best_j = dm_f2u(rd(19));
 				resumed = true;
 				active = true;
 			}
@@ -1623,6 +1628,7 @@ int srt_trace_waves_per_simd(int has_models, int use_bvh) {
 }
 int srt_scan_suspend_min(void) { return SRT_SCAN_SUSPEND_MIN; }
 int srt_scan_queue_in_hbm(void) { return SRT_SQ_GLOBAL; }
+int srt_bvh_suspends(void) { return SRT_BVH_SUSPEND; }
 int srt_sub_job_items(int has_models, int use_bvh) { return !has_models ? SRT_SUB_PLAIN : use_bvh ? SRT_SUB_BVH : SRT_SUB_MODELS; }
 
 int srt_trace_lds_floats(int has_models, int use_bvh) {

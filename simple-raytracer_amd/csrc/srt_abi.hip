@@ -609,7 +609,7 @@ static int update_scene_impl(srt_tracer *t, const srt_shape *shapes, size_t n_sh
 		if (s.type != SRT_SHAPE_SPHERE && s.type != SRT_SHAPE_PLANE && s.type != SRT_SHAPE_MODEL) continue; // ignored, as render.cl:301-366
 		const uint32_t block_cap = s.type == SRT_SHAPE_SPHERE ? 4u : 2u;
 		// array scan: a big model sits alone in its block (data_off's top bit marks the block until the headers are built)
-		const bool big_model = !use_bvh && s.type == SRT_SHAPE_MODEL && s.shape.model.num_triangles >= (uint32_t)srt_scan_suspend_min();
+		const bool big_model = (!use_bvh || srt_bvh_suspends()) && s.type == SRT_SHAPE_MODEL && s.shape.model.num_triangles >= (uint32_t)srt_scan_suspend_min();
 		const bool prev_big = !runs.empty() && (runs.back().data_off >> 31);
 		if (runs.empty() || runs.back().type != s.type || runs.back().first_shape + runs.back().count != i || runs.back().count == block_cap || big_model || prev_big) {
 			pad_run();
@@ -931,7 +931,7 @@ int srt_trace(srt_tracer *t, const srt_render_data *options) {
 	int slots = t->num_cus * per_cu;
 	if (slots > SRT_WAVE_CTR_SLOTS) slots = SRT_WAVE_CTR_SLOTS; // one counter line per persistent wave
 
-	if (t->num_models > 0 && !t->bvh_active && srt_scan_queue_in_hbm()) // one block per persistent wave, two sets (overlapping batches)
+	if (t->num_models > 0 && (!t->bvh_active || srt_bvh_suspends()) && srt_scan_queue_in_hbm()) // one block per persistent wave, two sets (overlapping batches)
 		SRT_HIP(t, t->scan_queue.reserve((size_t)2 * SRT_WAVE_CTR_SLOTS * SRT_SCAN_QUEUE_FLOATS));
 
 	ReduceParams rp;

@@ -11,6 +11,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <deque>
+#include <future>
 #include <new>
 #include <string>
 #include <vector>
@@ -107,10 +108,18 @@ struct BvhBuilder {
 			}
 	}
 
-	uint32_t build(uint32_t b, uint32_t e, uint32_t depth) {
-		const uint32_t self = (uint32_t)nodes.size();
-		nodes.emplace_back();
-		if (depth > max_depth) max_depth = depth;
+	// Subtree over tris[b, e) appended to `out` (indices inside `out`; a node's skip = the index behind its subtree, which
+	// for the subtree's last nodes is out.size() at return). The two halves of a large range are built by two threads into
+	// vectors of their own and appended in order -- same nodes in the same order as the one-thread build, the ranges of
+	// `tris` the threads partition are disjoint -- down to `par` levels: 10^5 triangles 42 -> 13 ms on the GPU box's cores.
+	struct Stats {
+		uint32_t leaves = 0, max_depth = 0;
+	};
+	Stats build_into(std::vector<BvhNode> &out, uint32_t b, uint32_t e, uint32_t depth, int par) {
+		Stats st;
+		const uint32_t self = (uint32_t)out.size();
+		out.emplace_back();
+		st.max_depth = depth;
 		float lo[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, hi[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
 		float clo[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, chi[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
 		for (uint32_t i = b; i < e; i++)
@@ -118,13 +127,13 @@ struct BvhBuilder {
 				lo[a] = std::min(lo[a], tris[i].lo[a]), hi[a] = std::max(hi[a], tris[i].hi[a]);
 				clo[a] = std::min(clo[a], tris[i].c[a]), chi[a] = std::max(chi[a], tris[i].c[a]);
 			}
-		for (int a = 0; a < 3; a++) nodes[self].lo[a] = lo[a], nodes[self].hi[a] = hi[a];
+		for (int a = 0; a < 3; a++) out[self].lo[a] = lo[a], out[self].hi[a] = hi[a];
 		const uint32_t n = e - b;
 		if (n <= SRT_BVH_LEAF_MAX) {
-			nodes[self].leaf = (n << 28) | (rec_base + b);
-			nodes[self].skip = (uint32_t)nodes.size();
-			leaves++;
-			return self;
+			out[self].leaf = (n << 28) | (rec_base + b);
+			out[self].skip = (uint32_t)out.size();
+			st.leaves = 1;
+			return st;
 		}
 		// binned SAH over the three axes
 		constexpr int NB = 16;
@@ -187,10 +196,32 @@ struct BvhBuilder {
 			mid = b + n / 2;
 			std::nth_element(tris.begin() + b, tris.begin() + mid, tris.begin() + e, [a](const Tri &x, const Tri &y) { return x.c[a] < y.c[a]; });
 		}
-		nodes[self].leaf = 0;
-		build(b, mid, depth + 1);
-		build(mid, e, depth + 1);
-		nodes[self].skip = (uint32_t)nodes.size();
+		out[self].leaf = 0;
+		Stats sl, sr;
+		if (par > 0 && n >= 8192) {
+			std::vector<BvhNode> left, right;
+			auto fut = std::async(std::launch::async, [&] { return build_into(left, b, mid, depth + 1, par - 1); });
+			sr = build_into(right, mid, e, depth + 1, par - 1);
+			sl = fut.get(); // (rethrows what the other thread threw)
+			for (std::vector<BvhNode> *sub : {&left, &right}) {
+				const uint32_t off = (uint32_t)out.size();
+				out.insert(out.end(), sub->begin(), sub->end());
+				for (size_t i = off; i < out.size(); i++) out[i].skip += off;
+			}
+		} else {
+			sl = build_into(out, b, mid, depth + 1, 0);
+			sr = build_into(out, mid, e, depth + 1, 0);
+		}
+		out[self].skip = (uint32_t)out.size();
+		st.leaves = sl.leaves + sr.leaves;
+		st.max_depth = std::max(sl.max_depth, sr.max_depth);
+		return st;
+	}
+	uint32_t build(uint32_t b, uint32_t e, uint32_t depth) {
+		const uint32_t self = (uint32_t)nodes.size();
+		const Stats st = build_into(nodes, b, e, depth, 3); // up to 8 subtrees at a time
+		leaves += st.leaves;
+		if (st.max_depth > max_depth) max_depth = st.max_depth;
 		return self;
 	}
 

@@ -330,9 +330,10 @@ __device__ __forceinline__ void test_spheres4(const Blk16 &s, f3 org, f3 dir, in
 
 // render.cl:206-221 against TWO planes (one 64-byte block {p, 0, n, 0} x 2; a run's last block is filled with a
 // plane of normal 0: denom == 0, never a hit)
-__device__ __forceinline__ void test_planes2(const Blk16 &b, f3 org, f3 dir, int idx0, float &tmin, int &best) {
+__device__ __forceinline__ void test_planes2(const Blk16 &b, uint32_t count, f3 org, f3 dir, int idx0, float &tmin, int &best) {
 #pragma unroll
 	for (int i = 0; i < 2; i++) {
+		if (i == 1 && count < 2u) break; // (wave-uniform) a run's last block may hold one plane: the filler's test, division included, is skipped
 		f3 n = mk(b.v[8 * i + 4], b.v[8 * i + 5], b.v[8 * i + 6]);
 		float denom = dot3(n, dir);
 		float t = dot3(n, mk(b.v[8 * i] - org.x, b.v[8 * i + 1] - org.y, b.v[8 * i + 2] - org.z)) / denom;
@@ -922,7 +923,7 @@ __global__ __launch_bounds__(64, USE_BVH ? SRT_TRACE_WAVES_PER_SIMD_BVH : HAS_MO
 						if (type1 == SRT_SHAPE_SPHERE + 1u) {
 							if (on) test_spheres4(b, org, dir, base, tmin, best);
 						} else if (type1 == SRT_SHAPE_PLANE + 1u) {
-							if (on) test_planes2(b, org, dir, base, tmin, best);
+							if (on) test_planes2(b, (code >> 2) & 7u, org, dir, base, tmin, best);
 						} else if (HAS_MODELS && type1 == SRT_SHAPE_MODEL + 1u) {
 							// the model's own box first, exactly as the reference (render.cl:316-323), then its triangles
 							const bool enter0 = on && test_aabb(b.v[0], b.v[1], b.v[2], b.v[4], b.v[5], b.v[6], org, inv, tmin);

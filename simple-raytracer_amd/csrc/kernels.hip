@@ -291,11 +291,12 @@ __device__ __forceinline__ uint32_t f2u(float f) { return __float_as_uint(f); }
 // run's last block with spheres of r*r = -inf, whose discriminant is -inf or NaN: never a hit). Straight-line:
 // the four tests are independent chains the scheduler can interleave, and the four square roots share ONE
 // small-argument guard (sqrt_ieee above) instead of a branch each. Updates the lane's closest hit in array order.
-__device__ __forceinline__ void test_spheres4(const Blk16 &s, f3 org, f3 dir, int idx0, float &tmin, int &best) {
+template <int N>
+__device__ __forceinline__ void test_spheres(const Blk16 &s, f3 org, f3 dir, int idx0, float &tmin, int &best) {
 	float bq[4], disc[4], sq[4];
 	bool tiny = false;
 #pragma unroll
-	for (int i = 0; i < 4; i++) {
+	for (int i = 0; i < N; i++) {
 		f3 L = mk(s.v[4 * i] - org.x, s.v[4 * i + 1] - org.y, s.v[4 * i + 2] - org.z);
 		bq[i] = dot3(L, dir);
 		float c = dot3(L, L) - s.v[4 * i + 3];
@@ -307,17 +308,17 @@ __device__ __forceinline__ void test_spheres4(const Blk16 &s, f3 org, f3 dir, in
 #ifndef SRT_NO_FAST_SQRT
 	if (__builtin_expect(tiny, 0)) {
 #pragma unroll
-		for (int i = 0; i < 4; i++) sq[i] = __builtin_sqrtf(disc[i]);
+		for (int i = 0; i < N; i++) sq[i] = __builtin_sqrtf(disc[i]);
 	} else {
 #pragma unroll
-		for (int i = 0; i < 4; i++) sq[i] = sqrt_core(disc[i]);
+		for (int i = 0; i < N; i++) sq[i] = sqrt_core(disc[i]);
 	}
 #else
 #pragma unroll
-	for (int i = 0; i < 4; i++) sq[i] = dm_sqrtf(disc[i]);
+	for (int i = 0; i < N; i++) sq[i] = dm_sqrtf(disc[i]);
 #endif
 #pragma unroll
-	for (int i = 0; i < 4; i++) {
+	for (int i = 0; i < N; i++) {
 		float t = bq[i] - sq[i];
 		if (t < 0.0f) t = bq[i] + sq[i];
 		bool hit = !(disc[i] < 0.0f) && !(t < 0.0f);
@@ -921,7 +922,11 @@ __global__ __launch_bounds__(64, USE_BVH ? SRT_TRACE_WAVES_PER_SIMD_BVH : HAS_MO
 						const uint32_t type1 = code & 3u; // shape type + 1; 0 = no block
 						const bool on = !SUSPEND || (part && bidx >= pos);
 						if (type1 == SRT_SHAPE_SPHERE + 1u) {
-							if (on) test_spheres4(b, org, dir, base, tmin, best);
+							if (on) {
+								// (wave-uniform) a run's last block may hold one or two spheres: the fillers' tests are skipped
+								if (((code >> 2) & 7u) <= 2u) test_spheres<2>(b, org, dir, base, tmin, best);
+								else test_spheres<4>(b, org, dir, base, tmin, best);
+							}
 						} else if (type1 == SRT_SHAPE_PLANE + 1u) {
 							if (on) test_planes2(b, (code >> 2) & 7u, org, dir, base, tmin, best);
 						} else if (HAS_MODELS && type1 == SRT_SHAPE_MODEL + 1u) {

@@ -307,6 +307,7 @@ def main():
             trace_ms.append(a)
             resolve_ms.append(b)
             kernel_only_ms.append(t.last_trace_kernel_ms())
+            step.launches = t.last_trace_launches()
 
     def fence():
         torch.cuda.synchronize(dev)
@@ -315,6 +316,7 @@ def main():
         torch.cuda.synchronize(dev)
 
     step.full = None
+    step.launches = (1, False)
 
     for _ in range(args.warmup):
         step(False)
@@ -400,11 +402,14 @@ def main():
             "roofline": {
                 "bound": "valu", "achieved": round(achieved, 3), "peak": round(VALU_PEAK_LANE_OPS / 1e12, 1), "unit": "Tlane-op/s",
                 "frac": round(achieved * 1e12 / VALU_PEAK_LANE_OPS, 4), "traffic": traffic,
-                "kernel": "srt_trace_kernel", "algorithmic_ops_per_launch": int(ops // world),
+                "kernel": "srt_trace_kernel", "algorithmic_ops_per_launch": int(ops // world // max(step.launches[0], 1)),
+                "launches_per_step": step.launches[0],
+                **({"launch_time": "the step's launches overlap on two streams (srt_trace): `achieved` = ops of the step / span from the first launch's start to the last one's end, "
+                                   "not ops per launch / a launch's own duration (a launch shares the GPU with its neighbour for part of its life)"} if step.launches[1] else {}),
                 "note": "VALU-issue roofline (SURVEY.md §8d/H8): 256 CU x 4 SIMD x 32 lanes x 2.4 GHz; ops = W_ops formula over exact kernel counters",
                 "hbm": {"achieved": round(nbytes / world / kt / 1e9, 2), "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                        "frac": round(nbytes / world / kt / HBM_PEAK, 6), "design_bytes_per_launch": int(nbytes // world),
-                        "algorithmic_bytes_per_launch": int(nbytes_alg // world),
+                        "frac": round(nbytes / world / kt / HBM_PEAK, 6), "design_bytes_per_launch": int(nbytes // world // max(step.launches[0], 1)),
+                        "algorithmic_bytes_per_launch": int(nbytes_alg // world // max(step.launches[0], 1)),
                         "note": "design bytes = algorithmic bytes (SURVEY.md 8d W_bytes) + 24 B per path of radiance written by the trace kernel and read by the ordered reduction"},
             },
         }

@@ -169,9 +169,13 @@ int srt_debug_counters(srt_tracer *t, uint64_t out[18]);
  * the most recent resolve, from HIP events recorded on the handle's stream (milliseconds).
  * Synchronises the stream. */
 int srt_last_kernel_ms(srt_tracer *t, float *trace_ms, float *resolve_ms);
-/* The same for srt_trace_kernel alone: the sum over the dispatch's sample batches of each
- * launch's own event pair (the ordered reductions between batches are not counted). */
+/* The same for srt_trace_kernel alone: one launch per sample batch of the dispatch. Batches that follow one another
+ * (a dispatch of one batch, the usual case): the sum of each launch's own event pair, the ordered reductions between them
+ * not counted. Overlapping batches (several batches: even and odd ones trace on two streams so that one batch's tail runs
+ * under the next batch): the span from the first launch's start to the last one's end. srt_last_trace_launches says which:
+ * the number of srt_trace_kernel launches of the last srt_trace and whether they overlapped. */
 int srt_last_trace_kernel_ms(srt_tracer *t, float *kernel_ms);
+int srt_last_trace_launches(const srt_tracer *t, int *launches, int *overlapped);
 /* Device pointers of the handle's buffers, for zero-copy hand-off (e.g. to a
  * torch.distributed gather): canvas = owned_rows*width*16 B, argb = owned_rows*width*4 B. */
 int srt_device_buffers(srt_tracer *t, void **canvas, size_t *canvas_bytes, void **argb, size_t *argb_bytes);

@@ -1241,6 +1241,13 @@ int srt_last_trace_kernel_ms(srt_tracer *t, float *kernel_ms) {
 	return SRT_OK;
 }
 
+int srt_last_trace_launches(const srt_tracer *t, int *launches, int *overlapped) {
+	if (!t) return SRT_ERR_INVALID;
+	if (launches) *launches = (int)(t->ev_k_used / 2);
+	if (overlapped) *overlapped = t->batches_overlapped ? 1 : 0;
+	return SRT_OK;
+}
+
 int srt_device_buffers(srt_tracer *t, void **canvas, size_t *canvas_bytes, void **argb, size_t *argb_bytes) {
 	if (!t) return SRT_ERR_INVALID;
 	if (canvas) *canvas = t->canvas;

@@ -24,7 +24,7 @@ LIB_PATH = Path(os.environ["SRT_LIB"]) if os.environ.get("SRT_LIB") else PKG / "
 ABI_SYMBOLS = [
     "srt_create", "srt_destroy", "srt_last_error", "srt_set_skybox", "srt_update_scene", "srt_clear_canvas",
     "srt_render", "srt_render_async", "srt_trace", "srt_set_radiance_budget", "srt_resolve", "srt_resolve_external", "srt_synchronize", "srt_read_canvas", "srt_read_argb",
-    "srt_get_counters", "srt_set_count_triangles", "srt_reset_counters", "srt_last_kernel_ms", "srt_last_trace_kernel_ms",
+    "srt_get_counters", "srt_set_count_triangles", "srt_reset_counters", "srt_last_kernel_ms", "srt_last_trace_kernel_ms", "srt_last_trace_launches",
     "srt_device_buffers", "srt_bind_canvas", "srt_bind_stream", "srt_set_partition",
     "srt_partition_owned_rows", "srt_partition_padded_rows", "srt_partition_global_row",
     "srt_partition_unpermute", "srt_selftest_math", "srt_version", "srt_set_acceleration", "srt_acceleration_info", "srt_bvh_build_host", "srt_bvh_wide_host", "srt_debug_counters",
@@ -318,6 +318,13 @@ class Tracer:
         a, b = C.c_float(), C.c_float()
         self._check(self.lib.srt_last_kernel_ms(self._h, C.byref(a), C.byref(b)))
         return a.value, b.value
+
+    def last_trace_launches(self):
+        """(srt_trace_kernel launches of the last trace = its sample batches, whether they overlapped on two streams)"""
+        n, o = C.c_int(0), C.c_int(0)
+        self.lib.srt_last_trace_launches.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        self._check(self.lib.srt_last_trace_launches(self._h, C.byref(n), C.byref(o)))
+        return n.value, bool(o.value)
 
     def last_trace_kernel_ms(self):
         a = C.c_float()

@@ -14,6 +14,7 @@
 #include <future>
 #include <new>
 #include <string>
+#include <system_error>
 #include <vector>
 
 #include "../../include/srt_abi.h"
@@ -200,9 +201,13 @@ struct BvhBuilder {
 		Stats sl, sr;
 		if (par > 0 && n >= 8192) {
 			std::vector<BvhNode> left, right;
-			auto fut = std::async(std::launch::async, [&] { return build_into(left, b, mid, depth + 1, par - 1); });
+			std::future<Stats> fut;
+			try {
+				fut = std::async(std::launch::async, [&] { return build_into(left, b, mid, depth + 1, par - 1); });
+			} catch (const std::system_error &) { // no thread to be had: this one does both halves
+			}
 			sr = build_into(right, mid, e, depth + 1, par - 1);
-			sl = fut.get(); // (rethrows what the other thread threw)
+			sl = fut.valid() ? fut.get() /* (rethrows what the other thread threw) */ : build_into(left, b, mid, depth + 1, 0);
 			for (std::vector<BvhNode> *sub : {&left, &right}) {
 				const uint32_t off = (uint32_t)out.size();
 				out.insert(out.end(), sub->begin(), sub->end());

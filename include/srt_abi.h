@@ -165,6 +165,10 @@ int srt_reset_counters(srt_tracer *t);
  * waves per CU and out[9] = workgroups of the most recent trace launch; out[10..17] = per-phase wave cycles
  * (extend, sky ring, shade, park, deliver, refill, loop head, whole kernel) of a -DSRT_PHASE_CLOCK build, else 0. */
 int srt_debug_counters(srt_tracer *t, uint64_t out[18]);
+/* Development builds with -DSRT_REGION_COUNT only (the product build writes nothing and sets *written = 0): for each
+ * region of the trace kernel, in the order of SRT_REGION_LIST (csrc/kernels.hip), {times a wave ran it, lanes that ran it}
+ * summed since the last srt_reset_counters; scripts/isa_phase_mix.py multiplies them with the static instruction mix. */
+int srt_debug_region_counters(srt_tracer *t, uint64_t *out, int capacity, int *written);
 /* Device time of the most recent srt_trace (trace kernel(s) + ordered reduction) and of
  * the most recent resolve, from HIP events recorded on the handle's stream (milliseconds).
  * Synchronises the stream. */

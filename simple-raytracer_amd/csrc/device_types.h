@@ -77,7 +77,12 @@ typedef srt_bvh_node BvhNode; /* include/srt_types.h */
  * summed on the host when asked for: thousands of waves ending together on three shared atomics
  * cost a small dispatch 100 us (profiles/README.md). Launches of a handle are stream-ordered and a
  * launch has one wave per index, so a plain read-modify-write is enough. */
+#define SRT_REGION_MAX 48 /* kernels.hip SRT_REGION_LIST: regions of the trace kernel a -DSRT_REGION_COUNT build counts (waves, lanes) for */
+#ifdef SRT_REGION_COUNT
+#define SRT_WAVE_CTR_STRIDE (16 + 2 * SRT_REGION_MAX)
+#else
 #define SRT_WAVE_CTR_STRIDE 16 /* unsigned long long per wave: rays, sky, paths, tri, tri_pass_u, 3 diagnostics, 8 phase clocks (-DSRT_PHASE_CLOCK builds) */
+#endif
 #define SRT_WAVE_CTR_SLOTS 8192 /* >= CUs * 4 SIMDs * 8 waves; the buffer holds TWO such sets: sample batches alternate (their launches overlap) */
 
 enum { SRT_CTR_RAYS = 0, SRT_CTR_SKY, SRT_CTR_TRI, SRT_CTR_TRI_PASS_U, SRT_CTR_NAN, SRT_CTR_PATHS, SRT_CTR_QUEUE, SRT_CTR_WATCHDOG, SRT_CTR_QUEUE2, SRT_CTR_COUNT }; /* QUEUE / QUEUE2: work cursors of even / odd sample batches */

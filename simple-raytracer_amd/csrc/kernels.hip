@@ -36,6 +36,46 @@
 #include "detmath.h"
 #include "device_types.h"
 
+// ---- regions: where the trace kernel's instructions are executed (development aid) ------------------------------
+// SRT_REGION(NAME) marks the start of a stretch of the trace kernel that runs as often as its first statement. In the
+// product build it expands to nothing; scripts/isa_phase_mix.py reads the markers' source lines and assigns every
+// instruction of the compiled kernel (by its line-table entry) to the region it was written in. A -DSRT_REGION_COUNT
+// build counts, per region, how often a wave ran it and with how many lanes (two LDS words per region, summed per wave
+// into its counter line; srt_debug_region_counters): static instruction mix x measured frequency = the executed mix.
+#define SRT_REGION_LIST(X)                                                                                                             \
+	X(PROLOGUE) X(LOOP_HEAD) X(EXTEND_SETUP) X(EXTEND_GROUP) X(EXTEND_SUSPEND)                                                       \
+	X(EXTEND_SPHERES2_0) X(EXTEND_SPHERES2_1) X(EXTEND_SPHERES2_2) X(EXTEND_SPHERES4_0) X(EXTEND_SPHERES4_1) X(EXTEND_SPHERES4_2)   \
+	X(EXTEND_PLANES_0) X(EXTEND_PLANES_1) X(EXTEND_PLANES_2) X(EXTEND_MODEL_0) X(EXTEND_MODEL_1) X(EXTEND_MODEL_2)                   \
+	X(EXTEND_TRI_LOOP) X(EXTEND_BVH_STEP) X(EXTEND_FINISH) X(SKY_PUSH) X(SKY_RESOLVE) X(SHADE_HEAD) X(SHADE_POP) X(SHADE_WINNER)   \
+	X(SHADE_MESH_NORMAL) X(SHADE_MATERIAL) X(SHADE_BOUNCE) X(SHADE_OPAQUE) X(SHADE_GLASS) X(SHADE_REFRACT) X(SHADE_TAIL) X(PARK)     \
+	X(HANDIN) X(HANDIN_ORPHAN) X(REFILL_HEAD) X(REFILL_SCANQ) X(REFILL_LOOP) X(REFILL_OPEN) X(REFILL_FLUSH) X(REFILL_CURSOR)         \
+	X(REFILL_TAKE) X(CAMERA) X(LOOP_TAIL) X(EPILOGUE)
+enum SrtRegion {
+#define SRT_REGION_ENUM(n) R_##n,
+	SRT_REGION_LIST(SRT_REGION_ENUM)
+#undef SRT_REGION_ENUM
+	R_COUNT
+};
+static_assert(R_COUNT <= SRT_REGION_MAX, "device_types.h SRT_REGION_MAX");
+#ifdef SRT_REGION_COUNT
+#define SRT_REGION(name) region_hit(region_ctr, R_##name)
+#define SRT_REGION_SLOT(name, slot) region_hit(region_ctr, R_##name##_0 + (slot)) // a stretch compiled once per block slot of a group (test_block)
+#define SRT_RC_PARAM , uint32_t *region_ctr
+#define SRT_RC_ARG , region_ctr
+__device__ __forceinline__ void region_hit(uint32_t *ctr, int r) {
+	const unsigned long long m = __ballot(1); // the lanes that are here
+	if ((int)threadIdx.x == __ffsll((long long)m) - 1) {
+		atomicAdd(&ctr[2 * r], 1u);
+		atomicAdd(&ctr[2 * r + 1], (uint32_t)__popcll(m));
+	}
+}
+#else
+#define SRT_REGION(name)
+#define SRT_REGION_SLOT(name, slot)
+#define SRT_RC_PARAM
+#define SRT_RC_ARG
+#endif
+
 namespace {
 
 struct f3 {
@@ -64,7 +104,7 @@ __device__ __forceinline__ f3 cross3(f3 a, f3 b) {
 __device__ __forceinline__ float sqrt_ieee(float x) {
 #ifndef SRT_NO_FAST_SQRT
 	const uint32_t mag = dm_f2u(x) & 0x7fffffffu;
-	if (__builtin_expect((mag - 1u) < 0x0f7fffffu, 0)) return __builtin_sqrtf(x); // 0 < |x| < 2^-96
+	if (__builtin_expect((mag - 1u) < 0x0f7fffffu, 0)) return __builtin_sqrtf(x); // 0 < |x| < 2^-96 @rare
 	float s = __builtin_amdgcn_sqrtf(x); // within 1 ulp
 	const uint32_t si = dm_f2u(s);
 	float down = dm_u2f(si - 1u), up = dm_u2f(si + 1u);
@@ -134,7 +174,7 @@ __device__ __forceinline__ f3 div3(f3 a, float b) {
 		return mk(div_core(a.x, b, r), div_core(a.y, b, r), div_core(a.z, b, r));
 	}
 #endif
-	return a / b;
+	return a / b; // @rare (scripts/isa_phase_mix.py: behind a range guard, counted as never executed)
 }
 // the built-in normalize: a * rsqrt(dot(a, a)) with detmath.h's division-free rsqrt -- 15 plain instructions, no
 // transcendental, no guard (before: IEEE sqrt and three IEEE quotients behind a range check)
@@ -308,7 +348,7 @@ __device__ __forceinline__ void test_spheres(const Blk16 &s, f3 org, f3 dir, int
 #ifndef SRT_NO_FAST_SQRT
 	if (__builtin_expect(tiny, 0)) {
 #pragma unroll
-		for (int i = 0; i < N; i++) sq[i] = __builtin_sqrtf(disc[i]);
+		for (int i = 0; i < N; i++) sq[i] = __builtin_sqrtf(disc[i]); // @rare
 	} else {
 #pragma unroll
 		for (int i = 0; i < N; i++) sq[i] = sqrt_core(disc[i]);
@@ -430,11 +470,12 @@ __device__ __forceinline__ void test_pair(const Tri2 &t, f3 org, f3 dir, int idx
 
 template <bool COUNT_TRIS>
 __device__ __forceinline__ void test_triangles(const float *__restrict__ wtris, uint32_t first, uint32_t count, f3 org, f3 dir, int idx,
-                                               float &tmin, int &best, uint32_t &best_tri, uint32_t &n_tri_u) {
+                                               float &tmin, int &best, uint32_t &best_tri, uint32_t &n_tri_u SRT_RC_PARAM) {
 	const float *__restrict__ blk = wtris + (size_t)first * SRT_WTRI_FLOATS;
 	const uint32_t npair = ((count + 3u) >> 2) << 1; // pairs, always even
 	Tri2 a = ld_tri2(blk);
 	for (uint32_t b = 0; b < npair; b += 2) {
+		SRT_REGION(EXTEND_TRI_LOOP);
 		const Tri2 c = ld_tri2(blk + 18u * (b + 1u)); // in flight while `a` is tested
 		test_pair<COUNT_TRIS>(a, org, dir, idx, 2u * b, count, tmin, best, best_tri, n_tri_u);
 		a = ld_tri2(blk + 18u * (b + 2u)); // in flight while `c` is tested (one pair of slack is allocated past the end)
@@ -485,7 +526,7 @@ __device__ __forceinline__ void bvh_order2(float &ta, uint32_t &ra, float &tb, u
 
 template <bool COUNT_TRIS>
 __device__ __forceinline__ void walk_bvh(const float4 *__restrict__ blocks, BvhStackEntry *__restrict__ stack, uint32_t root, f3 org, f3 dir, int idx,
-                                         float &tmin, int &best, uint32_t &best_rec, uint32_t &best_j, uint32_t &n_tri, uint32_t &n_tri_u) {
+                                         float &tmin, int &best, uint32_t &best_rec, uint32_t &best_j, uint32_t &n_tri, uint32_t &n_tri_u SRT_RC_PARAM) {
 	// 1/d, or +-2^100 where |d| < 2^-100: (lo - o) * inv stays finite (no 0 * inf = NaN), and keeps its sign
 	f3 inv;
 	inv.x = dm_fabs(dir.x) >= 0x1p-100f ? 1.0f / dir.x : __builtin_copysignf(0x1p100f, dir.x);
@@ -496,6 +537,7 @@ __device__ __forceinline__ void walk_bvh(const float4 *__restrict__ blocks, BvhS
 	float top_t = 0.0f;
 	uint32_t sp = 0u;
 	while (cur != SRT_BVH_NONE) {
+		SRT_REGION(EXTEND_BVH_STEP);
 		const float4 *__restrict__ b = blocks + 8u * (size_t)(cur & SRT_BVH_INDEX_MASK);
 		// all eight quarters, whatever the block holds: loads predicated on what a lane will look at (7 of an inner block,
 		// 3 / 5 / 8 of a leaf) were 25 % slower, the clause of eight unconditional loads is what keeps them in flight together
@@ -723,7 +765,7 @@ struct Stage {
 // A path has ended with radiance c: into its sub-job's staging slot if that sub-job is still staged,
 // else (its buffer was needed and written out meanwhile) straight to HBM. f0 / f1 report which.
 template <uint32_t SUB>
-__device__ __forceinline__ void deliver(const Stage &st, float *__restrict__ stage, float *__restrict__ radiance, uint32_t item, f3 c, bool &f0, bool &f1) {
+__device__ __forceinline__ void deliver(const Stage &st, float *__restrict__ stage, float *__restrict__ radiance, uint32_t item, f3 c, bool &f0, bool &f1 SRT_RC_PARAM) {
 	const uint32_t d0 = item - st.base0, d1 = item - st.base1;
 	if (d0 < st.total0) {
 		float *s = stage + 3u * d0;
@@ -734,6 +776,7 @@ __device__ __forceinline__ void deliver(const Stage &st, float *__restrict__ sta
 		s[0] = c.x, s[1] = c.y, s[2] = c.z;
 		f1 = true;
 	} else {
+		SRT_REGION(HANDIN_ORPHAN);
 		// The path outlived its staging buffer, which has been written out with a stale value in this item's place: store
 		// the radiance directly -- after that earlier store of this wave has been acknowledged. The buffer left long ago
 		// (a path's life time ago), so the wait returns at once; it only pins the order.
@@ -752,10 +795,11 @@ __device__ __forceinline__ void deliver(const Stage &st, float *__restrict__ sta
 // paths: mask *= sky; color += mask (render.cl:464-465). Called with all 64 lanes in
 // wave-uniform control flow.
 template <uint32_t SUB>
-__device__ __forceinline__ void resolve_ring(const TraceParams &p, const float *__restrict__ ring, uint32_t n, Stage &st, float *__restrict__ stage, int lane) {
+__device__ __forceinline__ void resolve_ring(const TraceParams &p, const float *__restrict__ ring, uint32_t n, Stage &st, float *__restrict__ stage, int lane SRT_RC_PARAM) {
 	asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 	bool f0 = false, f1 = false;
 	if ((uint32_t)lane < n) {
+		SRT_REGION(SKY_RESOLVE);
 		constexpr uint32_t RC = SRT_RING_CAP;
 		const f3 d = mk(ring[0 * RC + lane], ring[1 * RC + lane], ring[2 * RC + lane]);
 		f3 m = mk(ring[3 * RC + lane], ring[4 * RC + lane], ring[5 * RC + lane]);
@@ -763,7 +807,7 @@ __device__ __forceinline__ void resolve_ring(const TraceParams &p, const float *
 		const uint32_t item = dm_f2u(ring[9 * RC + lane]);
 		m = m * sky_box(p, d);
 		c = c + m;
-		deliver<SUB>(st, stage, p.radiance, item, c, f0, f1);
+		deliver<SUB>(st, stage, p.radiance, item, c, f0, f1 SRT_RC_ARG);
 	}
 	st.pend0 -= (uint32_t)__popcll(__ballot(f0));
 	st.pend1 -= (uint32_t)__popcll(__ballot(f1));
@@ -848,6 +892,11 @@ __global__ __launch_bounds__(64, USE_BVH ? SRT_TRACE_WAVES_PER_SIMD_BVH : HAS_MO
 	float *__restrict__ ring = stage + 2u * SUB * 3u;                          // [10][64] escaped paths awaiting their sky lookup
 	float *__restrict__ hq = ring + 10u * (uint32_t)SRT_RING_CAP;                                 // [16..18][HQ] paths that hit, awaiting their bounce (FIFO)
 	constexpr uint32_t HQ = USE_BVH ? SRT_HQ_CAP_BVH : SRT_HQ_CAP;
+#ifdef SRT_REGION_COUNT
+	uint32_t *region_ctr = reinterpret_cast<uint32_t *>(hq + (HAS_MODELS ? (USE_BVH ? 18u : 17u) : 16u) * HQ + (HAS_MODELS && !USE_BVH && !SRT_SQ_GLOBAL ? 19u * 64u : 0u));
+	for (int i = lane; i < 2 * SRT_REGION_MAX; i += 64) region_ctr[i] = 0u;
+	__syncthreads();
+#endif
 	// array-scan kernels: rays waiting for the triangle scan of a big model (stack of 64 records x 19 fields)
 	constexpr bool SUSPEND = HAS_MODELS && (!USE_BVH || SRT_BVH_SUSPEND);
 	constexpr uint32_t SQ = SRT_SQ_GLOBAL ? (uint32_t)SRT_SQ_CAP : 64u;
@@ -887,7 +936,9 @@ __global__ __launch_bounds__(64, USE_BVH ? SRT_TRACE_WAVES_PER_SIMD_BVH : HAS_MO
 	uint32_t idle_spins = 0;
 
 	SRT_CLK_DECL;
+	SRT_REGION(PROLOGUE);
 	for (;;) {
+		SRT_REGION(LOOP_HEAD);
 		bool hit = false, missed = false, fin = false;
 		bool suspended = false; // SUSPEND: the lane's ray went to the scan queue in this iteration
 		w_iter++;
@@ -896,6 +947,7 @@ __global__ __launch_bounds__(64, USE_BVH ? SRT_TRACE_WAVES_PER_SIMD_BVH : HAS_MO
 		if (__any(active)) {
 			if (nb > 0) w_rays += (unsigned long long)__popcll(__ballot(active && !(SUSPEND && resumed))); // a resumed ray was counted when it set out
 			if (active) {
+				SRT_REGION(EXTEND_SETUP);
 				if (nb <= 0) { // render.cl:403: no bounce loop at all -> colour 0
 					fin = true;
 				} else {
@@ -918,18 +970,27 @@ __global__ __launch_bounds__(64, USE_BVH ? SRT_TRACE_WAVES_PER_SIMD_BVH : HAS_MO
 					// the three blocks of a group are fetched with four scalar loads issued together: one scalar-memory
 					// round trip per group (a 7-shape scene is one group). The mesh kernels, whose triangle loops need
 					// the scalar registers, fetch the blocks of a group one by one instead.
-					auto test_block = [&](const Blk16 &b, uint32_t code, int base, uint32_t bidx) {
+					auto test_block = [&](const Blk16 &b, uint32_t code, int base, uint32_t bidx, int slot) {
 						const uint32_t type1 = code & 3u; // shape type + 1; 0 = no block
 						const bool on = !SUSPEND || (part && bidx >= pos);
 						if (type1 == SRT_SHAPE_SPHERE + 1u) {
 							if (on) {
 								// (wave-uniform) a run's last block may hold one or two spheres: the fillers' tests are skipped
-								if (((code >> 2) & 7u) <= 2u) test_spheres<2>(b, org, dir, base, tmin, best);
-								else test_spheres<4>(b, org, dir, base, tmin, best);
+								if (((code >> 2) & 7u) <= 2u) {
+									SRT_REGION_SLOT(EXTEND_SPHERES2, slot);
+									test_spheres<2>(b, org, dir, base, tmin, best);
+								} else {
+									SRT_REGION_SLOT(EXTEND_SPHERES4, slot);
+									test_spheres<4>(b, org, dir, base, tmin, best);
+								}
 							}
 						} else if (type1 == SRT_SHAPE_PLANE + 1u) {
-							if (on) test_planes2(b, (code >> 2) & 7u, org, dir, base, tmin, best);
+							if (on) {
+								SRT_REGION_SLOT(EXTEND_PLANES, slot);
+								test_planes2(b, (code >> 2) & 7u, org, dir, base, tmin, best);
+							}
 						} else if (HAS_MODELS && type1 == SRT_SHAPE_MODEL + 1u) {
+							SRT_REGION_SLOT(EXTEND_MODEL, slot);
 							// the model's own box first, exactly as the reference (render.cl:316-323), then its triangles
 							const bool enter0 = on && test_aabb(b.v[0], b.v[1], b.v[2], b.v[4], b.v[5], b.v[6], org, inv, tmin);
 							bool scan0 = enter0;
@@ -942,6 +1003,7 @@ __global__ __launch_bounds__(64, USE_BVH ? SRT_TRACE_WAVES_PER_SIMD_BVH : HAS_MO
 								const bool now = queue_dry || n_want >= (uint32_t)SRT_SCAN_NOW_MIN || sq_count + sq_pushed + n_want > SQ || __any(enter0 && resumed);
 								if (!now) {
 									if (enter0) {
+										SRT_REGION(EXTEND_SUSPEND);
 										const uint32_t e = sq_count + sq_pushed + __builtin_amdgcn_mbcnt_hi((uint32_t)(want >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)want, 0u));
 										sq[0 * SQ + e] = org.x, sq[1 * SQ + e] = org.y, sq[2 * SQ + e] = org.z;
 										sq[3 * SQ + e] = dir.x, sq[4 * SQ + e] = dir.y, sq[5 * SQ + e] = dir.z;
@@ -968,24 +1030,25 @@ __global__ __launch_bounds__(64, USE_BVH ? SRT_TRACE_WAVES_PER_SIMD_BVH : HAS_MO
 							}
 							if (scan0) {
 								if (USE_BVH) {
-									walk_bvh<COUNT_TRIS>(bvh_blocks, bvh_stack, f2u(b.v[3]), org, dir, base, tmin, best, best_tri, best_j, n_tri, n_tri_u);
+									walk_bvh<COUNT_TRIS>(bvh_blocks, bvh_stack, f2u(b.v[3]), org, dir, base, tmin, best, best_tri, best_j, n_tri, n_tri_u SRT_RC_ARG);
 								} else {
 									if (COUNT_TRIS) n_tri += f2u(b.v[7]);
-									test_triangles<COUNT_TRIS>(wtris, f2u(b.v[3]), f2u(b.v[7]), org, dir, base, tmin, best, best_tri, n_tri_u);
+									test_triangles<COUNT_TRIS>(wtris, f2u(b.v[3]), f2u(b.v[7]), org, dir, base, tmin, best, best_tri, n_tri_u SRT_RC_ARG);
 								}
 							}
 							if (((code >> 2) & 7u) > 1u && on && test_aabb(b.v[8], b.v[9], b.v[10], b.v[12], b.v[13], b.v[14], org, inv, tmin)) {
 								if (USE_BVH) {
-									walk_bvh<COUNT_TRIS>(bvh_blocks, bvh_stack, f2u(b.v[11]), org, dir, base + 1, tmin, best, best_tri, best_j, n_tri, n_tri_u);
+									walk_bvh<COUNT_TRIS>(bvh_blocks, bvh_stack, f2u(b.v[11]), org, dir, base + 1, tmin, best, best_tri, best_j, n_tri, n_tri_u SRT_RC_ARG);
 								} else {
 									if (COUNT_TRIS) n_tri += f2u(b.v[15]);
-									test_triangles<COUNT_TRIS>(wtris, f2u(b.v[11]), f2u(b.v[15]), org, dir, base + 1, tmin, best, best_tri, n_tri_u);
+									test_triangles<COUNT_TRIS>(wtris, f2u(b.v[11]), f2u(b.v[15]), org, dir, base + 1, tmin, best, best_tri, n_tri_u SRT_RC_ARG);
 								}
 							}
 						}
 					};
 					const int n_groups = p.num_runs;
 					for (int g = 0; g < n_groups; g++) {
+						SRT_REGION(EXTEND_GROUP);
 						float gh[4];
 						ld_uniform<4, 16>(reinterpret_cast<const float *>(runs + g), gh);
 						const uint32_t code = f2u(gh[0]);
@@ -1007,24 +1070,25 @@ __global__ __launch_bounds__(64, USE_BVH ? SRT_TRACE_WAVES_PER_SIMD_BVH : HAS_MO
 								b.v[8] = q2.x, b.v[9] = q2.y, b.v[10] = q2.z, b.v[11] = q2.w, b.v[12] = q3.x, b.v[13] = q3.y, b.v[14] = q3.z, b.v[15] = q3.w;
 								return b;
 							};
-							test_block(ld_lds(0), lcode & 255u, f0, 0u);
-							if ((lcode >> 8) & 255u) test_block(ld_lds(1), (lcode >> 8) & 255u, f1, 0u);
-							if ((lcode >> 16) & 255u) test_block(ld_lds(2), (lcode >> 16) & 255u, f2, 0u);
+							test_block(ld_lds(0), lcode & 255u, f0, 0u, 0);
+							if ((lcode >> 8) & 255u) test_block(ld_lds(1), (lcode >> 8) & 255u, f1, 0u, 1);
+							if ((lcode >> 16) & 255u) test_block(ld_lds(2), (lcode >> 16) & 255u, f2, 0u, 2);
 						} else if (!HAS_MODELS) {
 							const Blk16 b0 = ld_blk16(gd), b1 = ld_blk16(gd + 16), b2 = ld_blk16(gd + 32);
 #ifdef SRT_PHASE_CLOCK_LOADS
 							asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 							SRT_CLK(3); // (diagnosis) time until the group's scalar loads have arrived, booked on the PARK slot
 #endif
-							test_block(b0, code & 255u, (int)f2u(gh[1]), 0u);
-							test_block(b1, (code >> 8) & 255u, (int)f2u(gh[2]), 0u);
-							test_block(b2, (code >> 16) & 255u, (int)f2u(gh[3]), 0u);
+							test_block(b0, code & 255u, (int)f2u(gh[1]), 0u, 0);
+							test_block(b1, (code >> 8) & 255u, (int)f2u(gh[2]), 0u, 1);
+							test_block(b2, (code >> 16) & 255u, (int)f2u(gh[3]), 0u, 2);
 						} else {
-							test_block(ld_blk16(gd), code & 255u, (int)f2u(gh[1]), 3u * g);
-							if ((code >> 8) & 255u) test_block(ld_blk16(gd + 16), (code >> 8) & 255u, (int)f2u(gh[2]), 3u * g + 1u);
-							if ((code >> 16) & 255u) test_block(ld_blk16(gd + 32), (code >> 16) & 255u, (int)f2u(gh[3]), 3u * g + 2u);
+							test_block(ld_blk16(gd), code & 255u, (int)f2u(gh[1]), 3u * g, 0);
+							if ((code >> 8) & 255u) test_block(ld_blk16(gd + 16), (code >> 8) & 255u, (int)f2u(gh[2]), 3u * g + 1u, 1);
+							if ((code >> 16) & 255u) test_block(ld_blk16(gd + 32), (code >> 16) & 255u, (int)f2u(gh[3]), 3u * g + 2u, 2);
 						}
 					}
+					SRT_REGION(EXTEND_FINISH);
 					if (SUSPEND) resumed = false;
 					// a shape without a material counts as a miss (render.cl:404: material_index >= 0)
 					if (!SUSPEND || part) { // else: the ray waits in the scan queue, with all of its state
@@ -1044,12 +1108,13 @@ __global__ __launch_bounds__(64, USE_BVH ? SRT_TRACE_WAVES_PER_SIMD_BVH : HAS_MO
 		// ---- escaped paths queue for the sky (wave-uniform control flow) ----
 		const unsigned long long mm = __ballot(missed);
 		if (mm != 0ull) {
+			SRT_REGION(SKY_PUSH);
 			constexpr uint32_t RC = SRT_RING_CAP;
 			const uint32_t n_miss = (uint32_t)__popcll(mm);
 			const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mm, 0u));
 			uint32_t done = 0;
 			if (ring_count + n_miss > RC) { // does not fit: the sky lookups of what is queued first (ring_count lanes busy)
-				resolve_ring<SUB>(p, ring, ring_count, st, stage, lane);
+				resolve_ring<SUB>(p, ring, ring_count, st, stage, lane SRT_RC_ARG);
 				ring_count = 0;
 			}
 			while (done < n_miss) { // one round unless more lanes escaped than the ring holds (RC < 64)
@@ -1064,7 +1129,7 @@ __global__ __launch_bounds__(64, USE_BVH ? SRT_TRACE_WAVES_PER_SIMD_BVH : HAS_MO
 				ring_count += take;
 				done += take;
 				if (done < n_miss) {
-					resolve_ring<SUB>(p, ring, ring_count, st, stage, lane);
+					resolve_ring<SUB>(p, ring, ring_count, st, stage, lane SRT_RC_ARG);
 					ring_count = 0;
 				}
 			}
@@ -1077,6 +1142,7 @@ __global__ __launch_bounds__(64, USE_BVH ? SRT_TRACE_WAVES_PER_SIMD_BVH : HAS_MO
 		const uint32_t n_hit = (uint32_t)__popcll(hb);
 		const uint32_t n_ready = n_hit + hq_count;
 		if (n_ready >= (uint32_t)SRT_SHADE_MIN || n_ready > HQ || (queue_dry && n_ready > 0u)) {
+			SRT_REGION(SHADE_HEAD);
 			// lanes without a hit take the oldest waiting paths
 			const uint32_t n_free = 64u - n_hit;
 			const uint32_t n_pop = n_free < hq_count ? n_free : hq_count;
@@ -1085,6 +1151,7 @@ __global__ __launch_bounds__(64, USE_BVH ? SRT_TRACE_WAVES_PER_SIMD_BVH : HAS_MO
 				const unsigned long long fb = ~hb;
 				const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(fb >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)fb, 0u));
 				if (!hit && rank < n_pop) {
+					SRT_REGION(SHADE_POP);
 					uint32_t e = hq_head + rank;
 					e = e >= HQ ? e - HQ : e;
 					org = mk(hq[0 * HQ + e], hq[1 * HQ + e], hq[2 * HQ + e]);
@@ -1106,6 +1173,7 @@ __global__ __launch_bounds__(64, USE_BVH ? SRT_TRACE_WAVES_PER_SIMD_BVH : HAS_MO
 			}
 			w_shade++;
 			if (hit) {
+				SRT_REGION(SHADE_WINNER);
 				// ---- winner: normal, material (render.cl:311-312,337-343,361-362,372-375); org = hit position ----
 				int type, material_index;
 				f3 wv;
@@ -1133,6 +1201,7 @@ __global__ __launch_bounds__(64, USE_BVH ? SRT_TRACE_WAVES_PER_SIMD_BVH : HAS_MO
 				} else if (type == SRT_SHAPE_PLANE) {
 					nrm = wv;
 				} else if (HAS_MODELS) {
+					SRT_REGION(SHADE_MESH_NORMAL);
 					const srt_model *__restrict__ m = &p.shapes[best].shape.model;
 					const float *__restrict__ w = USE_BVH ? p.bvh_blocks + (size_t)(best_tri >> 2) * 32u + (best_tri & 3u) * SRT_BVH_TRI_FLOATS
 					                                      : wtris + (size_t)(first_wtri + best_tri) * SRT_WTRI_FLOATS;
@@ -1160,6 +1229,7 @@ __global__ __launch_bounds__(64, USE_BVH ? SRT_TRACE_WAVES_PER_SIMD_BVH : HAS_MO
 					color = mk(nrm.x * 0.5f + 0.5f, nrm.y * 0.5f + 0.5f, nrm.z * 0.5f + 0.5f); // render.cl:407-410
 					fin = true;
 				} else {
+					SRT_REGION(SHADE_MATERIAL);
 					float4 m0, m1, mc, me;
 					if (USE_LDS) {
 						const float4 *__restrict__ lm = lds + 2 * n_shapes + 4 * material_index;
@@ -1175,6 +1245,7 @@ __global__ __launch_bounds__(64, USE_BVH ? SRT_TRACE_WAVES_PER_SIMD_BVH : HAS_MO
 					if (bounce == nb - 1) {                                             // render.cl:415-416
 						fin = true;
 					} else {
+						SRT_REGION(SHADE_BOUNCE);
 						// cosine weighted direction: 6 draws (render.cl:421, 156-163)
 						float gx = random_normal(seed);
 						float gy = random_normal(seed);
@@ -1188,9 +1259,11 @@ __global__ __launch_bounds__(64, USE_BVH ? SRT_TRACE_WAVES_PER_SIMD_BVH : HAS_MO
 						f3 rough_dir = mix3(random_dir, reflected_dir, smoothness);
 						bool is_transparent = transmittance > random_float(seed);
 						if (!is_transparent) {
+							SRT_REGION(SHADE_OPAQUE);
 							dir = mix3(random_dir, rough_dir, (is_metallic || is_specular) ? 1.0f : 0.0f);
 							mask = mask * mix3(mcolor, mk(1.0f, 1.0f, 1.0f), is_specular ? 1.0f : 0.0f);
 						} else {
+							SRT_REGION(SHADE_GLASS);
 							f3 in_dir = reflect3(rough_dir, nrm);
 							// 1/ior and both Schlick r0 values come precomputed with the material (srt_update_scene)
 							float mu = front ? m1.z : ior;
@@ -1204,6 +1277,7 @@ __global__ __launch_bounds__(64, USE_BVH ? SRT_TRACE_WAVES_PER_SIMD_BVH : HAS_MO
 							if (reflected) {
 								dir = rough_dir;
 							} else {
+								SRT_REGION(SHADE_REFRACT);
 								f3 out_perp = (in_dir + nrm * cos_theta) * mu;
 								float lsq = (out_perp.x * out_perp.x + out_perp.y * out_perp.y) + out_perp.z * out_perp.z;
 								f3 out_parallel = nrm * (-sqrt_core(dm_fabs(1.0f - lsq)));
@@ -1211,6 +1285,7 @@ __global__ __launch_bounds__(64, USE_BVH ? SRT_TRACE_WAVES_PER_SIMD_BVH : HAS_MO
 								mask = mask * mcolor;
 							}
 						}
+						SRT_REGION(SHADE_TAIL);
 						dir = normalize3(dir);
 						org = pos + (nrm * dm_sign(dot3(nrm, dir))) * 0.001f; // render.cl:462
 						bounce++;
@@ -1222,6 +1297,7 @@ __global__ __launch_bounds__(64, USE_BVH ? SRT_TRACE_WAVES_PER_SIMD_BVH : HAS_MO
 		} else if (n_hit != 0u) {
 			// PARK: every hit waits in the queue; all lanes are free for new camera rays
 			if (hit) {
+				SRT_REGION(PARK);
 				uint32_t e = hq_head + hq_count + __builtin_amdgcn_mbcnt_hi((uint32_t)(hb >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)hb, 0u));
 				e = e >= HQ ? e - HQ : e;
 				hq[0 * HQ + e] = org.x, hq[1 * HQ + e] = org.y, hq[2 * HQ + e] = org.z;
@@ -1243,7 +1319,8 @@ __global__ __launch_bounds__(64, USE_BVH ? SRT_TRACE_WAVES_PER_SIMD_BVH : HAS_MO
 		// ---- paths that ended in this iteration hand in their radiance ----
 		if (__any(fin)) {
 			bool f0 = false, f1 = false;
-			if (fin) deliver<SUB>(st, stage, p.radiance, item, color, f0, f1);
+			SRT_REGION(HANDIN);
+			if (fin) deliver<SUB>(st, stage, p.radiance, item, color, f0, f1 SRT_RC_ARG);
 			const uint32_t n0 = (uint32_t)__popcll(__ballot(f0)), n1 = (uint32_t)__popcll(__ballot(f1));
 			st.pend0 -= n0, st.pend1 -= n1;
 			w_orphans += (uint32_t)__popcll(__ballot(fin)) - n0 - n1;
@@ -1251,10 +1328,12 @@ __global__ __launch_bounds__(64, USE_BVH ? SRT_TRACE_WAVES_PER_SIMD_BVH : HAS_MO
 
 		SRT_CLK(4);
 		// ================= REFILL: free lanes take new camera rays =================
+		SRT_REGION(REFILL_HEAD);
 		unsigned long long freeb = __ballot(!active);
 		uint32_t n_free = (uint32_t)__popcll(freeb);
 		if (SUSPEND && sq_count != 0u && n_free != 0u &&
 		    (queue_dry || (n_free >= (uint32_t)SRT_REFILL_MIN && sq_count >= (n_free < (uint32_t)SRT_SCAN_NOW_MIN ? n_free : (uint32_t)SRT_SCAN_NOW_MIN)))) {
+			SRT_REGION(REFILL_SCANQ);
 			// rays that wait for a big model's triangle scan come first: together they fill the wave for it
 			asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); // the records' stores have arrived (LDS, or HBM: acknowledged by the L2)
 			const uint32_t n_pop = n_free < sq_count ? n_free : sq_count;
@@ -1288,12 +1367,15 @@ __global__ __launch_bounds__(64, USE_BVH ? SRT_TRACE_WAVES_PER_SIMD_BVH : HAS_MO
 			bool got = false;
 			uint32_t off = 0, qpix = 0;
 			while (given < n_free) {
+				SRT_REGION(REFILL_LOOP);
 				const uint32_t cur_total = cur ? st.total1 : st.total0;
 				if (issued == cur_total) {
+					SRT_REGION(REFILL_OPEN);
 					// the current sub-job is handed out (or there is none yet): open the next one in the other buffer
 					const uint32_t o = cur ^ 1u;
 					const uint32_t o_total = o ? st.total1 : st.total0;
 					if (o_total != 0u) {
+						SRT_REGION(REFILL_FLUSH);
 						// It still holds the sub-job before the current one: write it out. Paths of it that are still on
 						// their way (pend != 0) deliver to HBM themselves when they end (deliver() orders their stores
 						// behind this one).
@@ -1304,6 +1386,7 @@ __global__ __launch_bounds__(64, USE_BVH ? SRT_TRACE_WAVES_PER_SIMD_BVH : HAS_MO
 						else st.total0 = 0u, st.pend0 = 0u;
 					}
 					if (chunk_cur == chunk_end) {
+						SRT_REGION(REFILL_CURSOR);
 						unsigned long long start = total_items;
 						if (own_chunks_end < (unsigned long long)total_items) { // else every chunk is some wave's first: nothing to ask the cursor for
 							if (lane == 0) start = atomicAdd((unsigned long long *)SRT_COLD(p).queue, (unsigned long long)SRT_COLD(p).job_items);
@@ -1332,6 +1415,7 @@ __global__ __launch_bounds__(64, USE_BVH ? SRT_TRACE_WAVES_PER_SIMD_BVH : HAS_MO
 					issued = 0;
 					continue;
 				}
+				SRT_REGION(REFILL_TAKE);
 				const uint32_t avail = cur_total - issued;
 				const uint32_t take = avail < n_free - given ? avail : n_free - given;
 				if (!active && !got && rank >= given && rank < given + take) {
@@ -1348,6 +1432,7 @@ __global__ __launch_bounds__(64, USE_BVH ? SRT_TRACE_WAVES_PER_SIMD_BVH : HAS_MO
 				w_paths += take;
 			}
 			if (got) {
+				SRT_REGION(CAMERA);
 				// ---- camera ray (render.cl:488,496-516) ----
 				const auto &c = SRT_COLD(p);
 				const uint32_t dq = (nbs >= SUB) ? (off >= nbs ? 1u : 0u) : off / nbs;
@@ -1375,6 +1460,7 @@ __global__ __launch_bounds__(64, USE_BVH ? SRT_TRACE_WAVES_PER_SIMD_BVH : HAS_MO
 		}
 
 		SRT_CLK(5);
+		SRT_REGION(LOOP_TAIL);
 		if (!__any(active) && hq_count == 0u && sq_count == 0u) {
 			if (queue_dry) break;
 			// Bounded: a wave that spins here without ever getting work leaves with the watchdog counter set instead of hanging.
@@ -1387,7 +1473,8 @@ __global__ __launch_bounds__(64, USE_BVH ? SRT_TRACE_WAVES_PER_SIMD_BVH : HAS_MO
 		}
 	}
 	// queue dry, no lane active, nothing parked: whatever is still staged is complete
-	if (ring_count != 0u) resolve_ring<SUB>(p, ring, ring_count, st, stage, lane);
+	SRT_REGION(EPILOGUE);
+	if (ring_count != 0u) resolve_ring<SUB>(p, ring, ring_count, st, stage, lane SRT_RC_ARG);
 	if (st.total0 != 0u) flush_stage(stage, p.radiance + 3ull * st.base0, st.total0, lane);
 	if (st.total1 != 0u) flush_stage(stage + SUB * 3u, p.radiance + 3ull * st.base1, st.total1, lane);
 
@@ -1419,6 +1506,13 @@ __global__ __launch_bounds__(64, USE_BVH ? SRT_TRACE_WAVES_PER_SIMD_BVH : HAS_MO
 		w[15] += __builtin_amdgcn_s_memtime() - clk_start;
 #endif
 	}
+#ifdef SRT_REGION_COUNT
+	__syncthreads();
+	{
+		unsigned long long *__restrict__ w = (unsigned long long *)SRT_COLD(p).wave_counters + (size_t)blockIdx.x * SRT_WAVE_CTR_STRIDE + 16;
+		for (int i = lane; i < 2 * SRT_REGION_MAX; i += 64) w[i] += region_ctr[i];
+	}
+#endif
 }
 
 // ---------------------------------------------------------------------------------
@@ -1640,7 +1734,11 @@ int srt_sub_job_items(int has_models, int use_bvh) { return !has_models ? SRT_SU
 int srt_trace_lds_floats(int has_models, int use_bvh) {
 	// two staging buffers of packed 12-byte items, the sky ring (10 fields), the hit queue (16..18 fields)
 	const int sub = srt_sub_job_items(has_models, use_bvh);
-	return 2 * sub * 3 + 10 * SRT_RING_CAP + (has_models ? (use_bvh ? 18 * SRT_HQ_CAP_BVH : 17 * SRT_HQ_CAP) : 16 * SRT_HQ_CAP) + (has_models && !use_bvh && !SRT_SQ_GLOBAL ? 19 * 64 : 0);
+	int n = 2 * sub * 3 + 10 * SRT_RING_CAP + (has_models ? (use_bvh ? 18 * SRT_HQ_CAP_BVH : 17 * SRT_HQ_CAP) : 16 * SRT_HQ_CAP) + (has_models && !use_bvh && !SRT_SQ_GLOBAL ? 19 * 64 : 0);
+#ifdef SRT_REGION_COUNT
+	n += 2 * SRT_REGION_MAX; // (waves, lanes) per region
+#endif
+	return n;
 }
 
 namespace {

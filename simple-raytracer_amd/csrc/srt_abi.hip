@@ -1408,6 +1408,30 @@ int srt_debug_counters(srt_tracer *t, uint64_t out[18]) {
 	return SRT_OK;
 }
 
+/* -DSRT_REGION_COUNT builds: per region of the trace kernel (kernels.hip SRT_REGION_LIST, in that order) how often a wave
+ * ran it and with how many lanes, summed over the waves since the last reset. *written = 0 in the product build. */
+int srt_debug_region_counters(srt_tracer *t, uint64_t *out, int capacity, int *written) {
+	if (!t || !out || !written || capacity < 0) return SRT_ERR_INVALID;
+	*written = 0;
+#ifdef SRT_REGION_COUNT
+	SRT_HIP(t, hipSetDevice(t->device));
+	std::vector<unsigned long long> w;
+	try {
+		w.resize((size_t)2 * SRT_WAVE_CTR_SLOTS * SRT_WAVE_CTR_STRIDE);
+	} catch (...) {
+		return fail(t, SRT_ERR_INVALID, "out of host memory");
+	}
+	SRT_HIP(t, hipMemcpyAsync(w.data(), t->wave_counters.ptr, w.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, t->stream));
+	SRT_HIP(t, hipStreamSynchronize(t->stream));
+	const int n = capacity < 2 * SRT_REGION_MAX ? capacity : 2 * SRT_REGION_MAX;
+	for (int k = 0; k < n; k++) out[k] = 0;
+	for (size_t i = 0; i < (size_t)2 * SRT_WAVE_CTR_SLOTS; i++)
+		for (int k = 0; k < n; k++) out[k] += w[i * SRT_WAVE_CTR_STRIDE + 16 + k];
+	*written = n;
+#endif
+	return SRT_OK;
+}
+
 /* test hook: build with triangle counters (instrumented kernel variant) */
 int srt_set_count_triangles(srt_tracer *t, int enable) {
 	if (!t) return SRT_ERR_INVALID;

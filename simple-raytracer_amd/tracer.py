@@ -27,7 +27,7 @@ ABI_SYMBOLS = [
     "srt_get_counters", "srt_set_count_triangles", "srt_reset_counters", "srt_last_kernel_ms", "srt_last_trace_kernel_ms", "srt_last_trace_launches",
     "srt_device_buffers", "srt_bind_canvas", "srt_bind_stream", "srt_set_partition",
     "srt_partition_owned_rows", "srt_partition_padded_rows", "srt_partition_global_row",
-    "srt_partition_unpermute", "srt_selftest_math", "srt_version", "srt_set_acceleration", "srt_acceleration_info", "srt_bvh_build_host", "srt_bvh_wide_host", "srt_debug_counters",
+    "srt_partition_unpermute", "srt_selftest_math", "srt_version", "srt_set_acceleration", "srt_acceleration_info", "srt_bvh_build_host", "srt_bvh_wide_host", "srt_debug_counters", "srt_debug_region_counters",
     "srt_comm_unique_id", "srt_comm_init", "srt_gather", "srt_resolve_gathered", "srt_gathered_buffers", "srt_read_gathered",
     "srt_group_create", "srt_group_destroy", "srt_group_last_error", "srt_group_size", "srt_group_tracer", "srt_group_set_skybox",
     "srt_group_set_acceleration", "srt_group_update_scene", "srt_group_clear_canvas", "srt_group_trace_and_gather", "srt_group_render",
@@ -293,6 +293,14 @@ class Tracer:
                 "phase_cycles": dict(zip(("extend", "ring", "shade", "park", "deliver", "refill", "head", "kernel"), v[10:18])),
                 # array-scan kernels without -DSRT_PHASE_CLOCK reuse the first two clock slots: big-model scans and the lanes in them
                 "scans": v[10], "scan_lanes": v[11]}
+
+    def debug_region_counters(self):
+        """[(waves, lanes)] per region of SRT_REGION_LIST for a -DSRT_REGION_COUNT build; [] for the product build."""
+        out = (C.c_uint64 * 128)()
+        n = C.c_int(0)
+        self.lib.srt_debug_region_counters.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.c_int, C.POINTER(C.c_int)]
+        self._check(self.lib.srt_debug_region_counters(self._h, out, 128, C.byref(n)))
+        return [(int(out[2 * i]), int(out[2 * i + 1])) for i in range(n.value // 2)]
 
     def reset_counters(self):
         self._check(self.lib.srt_reset_counters(self._h))

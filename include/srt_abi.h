@@ -275,8 +275,11 @@ int srt_pipeline_flush(srt_tracer *t, uint8_t *argb_out, long long *frame_delive
  * against IEEE `/` and sqrt (must be 0); out[9] = sum of the result bits of the built-in
  * normalize (detmath's division-free rsqrt), again for comparison with the host build; out[11] = mismatch count of the
  * RNG-scaling shortcuts (log of the raw count, theta from the raw count) against the plain forms
- * (must be 0). */
-int srt_selftest_math(srt_tracer *t, uint32_t stride, uint64_t out[12]);
+ * (must be 0); out[12] = mismatch count of the kernel's reciprocal-root square root against IEEE sqrt on
+ * the floats in [2^-96, inf) (all of them at stride 1; must be 0); out[13] = mismatch count of the camera
+ * rays' division by the image size through the host's reciprocal against IEEE `/` (must be 0);
+ * out[14..15] = 0 (reserved). */
+int srt_selftest_math(srt_tracer *t, uint32_t stride, uint64_t out[16]);
 
 /* Library / build identification, e.g. "srt-hip gfx950 parity fp-contract=off". */
 const char *srt_version(void);

@@ -205,6 +205,8 @@ def static_mix(kernel, flags, cache="/tmp/srt_phase_mix.hsaco"):
             if line in rare:
                 return "RARE", ()
             if body_lo <= line <= body_hi:
+                if region is None:
+                    region, depth = "PROLOGUE", d  # the kernel's lines before its first marker
                 for ml, name in markers:
                     if body_lo <= ml <= line:
                         region, depth = name, d
@@ -230,6 +232,11 @@ def static_mix(kernel, flags, cache="/tmp/srt_phase_mix.hsaco"):
             starts.add(insts[i + 1][0])
     res2 = [resolve(st) for st in stacks]
     res = [r for r, _ in res2]
+    # what the compiler hoisted out of the main loop (constants, invariant addresses) keeps the line it came from but runs
+    # once per wave: everything laid out before the loop's first instruction is prologue
+    first_loop = next((i for i, r in enumerate(res) if r == "LOOP_HEAD"), 0)
+    res = [("PROLOGUE" if i < first_loop and r != "RARE" else r) for i, r in enumerate(res)]
+    res2 = [((r, c[1]) if r == c[0] else (r, ())) for r, c in zip(res, res2)]
     copies = collections.defaultdict(set)
     for r, c in res2:
         if r and r != "RARE":

@@ -123,7 +123,22 @@ struct TraceParams {
 	int32_t use_bvh;          /* model records carry a BVH root instead of a first world triangle */
 	const float *bvh_blocks;  /* all models' 128-byte blocks (wide hierarchy above) */
 	float *scan_queue;        /* array scan: 19 x 64 floats per persistent wave (rays that wait for a big model's triangle scan) */
+	/* camera-ray set-up without per-lane integer or IEEE divisions (kernels.hip CAMERA; srt_abi.hip fills them per launch) */
+	float inv_f_width, inv_f_height;  /* 1.0f / f_width, 1.0f / f_height, correctly rounded on the host (srt_div_by_rcp in kernels.hip) */
+	uint32_t width_magic, width_shift; /* n / width = (mulhi(n, magic) + n) >> shift for n < 2^31 (srt_magic_u31) */
+	uint32_t rpb_magic, rpb_shift;     /* the same for rows_per_block */
+	uint32_t nbs_magic16;              /* n / batch_samples = (n * magic16) >> 16 for n < 256, when batch_samples < 128 (else unused) */
+	uint32_t _pad3;
 };
+
+/* n / d for 0 <= n < 2^31 as (mulhi(n, magic) + n) >> shift: Granlund & Montgomery's round-up method with shift = ceil(log2 d);
+ * for n below 2^31 the sum cannot overflow 32 bits (mulhi(n, magic) < n). d >= 1. */
+static inline void srt_magic_u31(uint32_t d, uint32_t *magic, uint32_t *shift) {
+	uint32_t l = 0;
+	while (l < 32 && ((uint64_t)1 << l) < d) l++;
+	*shift = l;
+	*magic = (uint32_t)((((uint64_t)1 << 32) * (((uint64_t)1 << l) - d)) / d + 1);
+}
 
 struct PrepassParams {
 	const srt_shape *shapes;
@@ -171,6 +186,6 @@ int srt_scan_queue_in_hbm(void); /* 1: TraceParams.scan_queue must point at SRT_
 int srt_bvh_suspends(void);
 void srt_launch_prepass(const PrepassParams &p, uint64_t total_wtris, void *stream);
 void srt_launch_resolve(const ResolveParams &p, void *stream);
-void srt_launch_selftest(unsigned long long *out12, uint32_t stride, void *stream);
+void srt_launch_selftest(unsigned long long *out16, uint32_t stride, void *stream);
 
 #endif

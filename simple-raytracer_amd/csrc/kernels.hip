@@ -134,6 +134,30 @@ __device__ __forceinline__ float sqrt_core(float x) {
 #endif
 }
 
+// Correctly rounded sqrt of a NORMAL x >= 2^-96 from v_rsq_f32 and one residual step: y ~ 1/sqrt(x) (1 ulp), s = x y (within
+// 2 ulp of the root), then s + (x - s s) (y / 2) rounded once (Markstein's form of the Newton step: the residual comes out of
+// one fma, and the correction is far below the distance of any root of a float from a rounding boundary). One transcendental
+// and four plain instructions, no compare / select pair (each of which costs wait states on gfx950, where a VALU may not read
+// an SGPR or VCC a VALU wrote in the two slots before): sqrt_core above is 1 + 8 and two such pairs.
+// EXHAUSTIVE: equal to __builtin_sqrtf on every float in [2^-96, inf) (scripts/microbench/exact_math_probe.hip;
+// srt_selftest_math out[12] repeats the sweep inside the library). Outside that range: NaN for negative x and NaN (as IEEE),
+// NaN for +inf (IEEE: inf), NaN for +-0 (IEEE: +-0), garbage for tiny x -- callers route those elsewhere or show that NaN and
+// the IEEE value act alike where the result goes.
+__device__ __forceinline__ float sqrt_rsq(float x) {
+	const float y = __builtin_amdgcn_rsqf(x);
+	const float s = x * y, h = 0.5f * y;
+	const float r = __builtin_fmaf(-s, s, x);
+	return __builtin_fmaf(r, h, s);
+}
+// The same with the reciprocal root clamped to [0, 2^100] (v_med3_f32; a NaN becomes 0): additionally +-0 -> +-0. For
+// arguments that are -0, +0 or normal and >= 2^-96: Box-Muller's -2 log u for every u != 0 (u = 1 gives -0).
+__device__ __forceinline__ float sqrt_rsq_zero_ok(float x) {
+	const float y = __builtin_amdgcn_fmed3f(__builtin_amdgcn_rsqf(x), 0.0f, 0x1p100f);
+	const float s = x * y, h = 0.5f * y;
+	const float r = __builtin_fmaf(-s, s, x);
+	return __builtin_fmaf(r, h, s);
+}
+
 // ---- IEEE division with the operand scaling factored out ------------------------------
 // hipcc expands a / b into v_div_scale (x2), v_rcp, two Newton steps on the reciprocal,
 // q = a*r with two residual corrections, v_div_fmas and v_div_fixup: 11 instructions, one
@@ -159,6 +183,14 @@ __device__ __forceinline__ float div_core(float a, float b, float r) {
 	m = __builtin_fmaf(-b, q, a);
 	return __builtin_fmaf(m, r, q);
 }
+// a / b with y = the CORRECTLY ROUNDED 1 / b (an IEEE quotient made on the host), for 0 <= a < 2^32 that is zero or at least
+// 2^-40 and 1 <= b <= 2^31: the camera's (pixel + jitter) / image size. q0 = a y is within 2 ulp of a / b, the first
+// correction leaves a faithful quotient (its residual a - b q0 is exact in one fma), and for a faithful q and y = RN(1 / b)
+// RN(q + (a - b q) y) is the correctly rounded quotient (Markstein, IBM J. Res. Dev. 34, 1990, theorem 8.5; no step over- or
+// underflows in that range; a = +0 gives +0). Five plain instructions instead of the compiler's eleven, one of them
+// transcendental. scripts/microbench/exact_math_probe.hip (2^32 quotients over eight image sizes) and srt_selftest_math
+// compare it with `/` on the device.
+__device__ __forceinline__ float div_by_rcp(float a, float b, float y) { return div_core(a, b, y); }
 __device__ __forceinline__ bool div_num_ok(f3 a) {
 	const float ax = dm_fabs(a.x), ay = dm_fabs(a.y), az = dm_fabs(a.z);
 	const float mn = __builtin_fminf(__builtin_fminf(ax, ay), az); // v_min3 / v_max3: skip NaNs
@@ -223,7 +255,7 @@ __device__ __forceinline__ float random_float(uint32_t &seed) {
 // subnormal / inf / NaN handling can never trigger here), so the same bits.
 // EXP_BIAS = 127 for u itself; 159 when handed the count c = u * 2^32 instead (same mantissa,
 // exponent 32 higher, zero stays zero).
-template <int EXP_BIAS>
+template <int EXP_BIAS, bool ZERO_OK>
 __device__ __forceinline__ float log_unit_biased(float u) {
 	const float LN2_HI = 6.93138123e-01f, LN2_LO = 9.05800061e-06f;
 	const float L0 = 6.66666687e-01f, L1 = 4.00001287e-01f, L2 = 2.85499692e-01f, L3 = 2.33534276e-01f;
@@ -237,7 +269,14 @@ __device__ __forceinline__ float log_unit_biased(float u) {
 	// f is +0 or a multiple of 2^-24 in [-0.293, 0.415] and 2 + f lies in [1.7, 2.42]: inside the
 	// box of div_core (which also returns the +0 the division gives for f = +0)
 	const float den = 2.0f + f;
-#ifndef SRT_NO_FAST_DIV
+#if !defined(SRT_NO_FAST_DIV) && !defined(SRT_NO_LOG_DIV1)
+	// f / den from the raw v_rcp_f32 and ONE residual step. Not a general division: f takes 2^24 values here, and the quotient is
+	// the IEEE one for every single u the RNG can return (exhaustive: exact_math_probe.hip "log div D1"; srt_selftest_math
+	// out[1] compares this function with dm_logf on all 2^32 of them). 1 + 3 instructions (shared-reciprocal form: 1 + 7).
+	const float rc = __builtin_amdgcn_rcpf(den);
+	const float q0 = f * rc;
+	float s = __builtin_fmaf(__builtin_fmaf(-den, q0, f), rc, q0);
+#elif !defined(SRT_NO_FAST_DIV)
 	float s = div_core(f, den, rcp_refined(den));
 #else
 	float s = f / den;
@@ -247,13 +286,14 @@ __device__ __forceinline__ float log_unit_biased(float u) {
 	float hfsq = (0.5f * f) * f;
 	float dk = (float)k;
 	float r = dm_fmaf(dk, LN2_HI, f - (hfsq - dm_fmaf(s, hfsq + R, dk * LN2_LO)));
+	if (!ZERO_OK) return r; // the caller deals with u = 0 (for which r is some finite number)
 	// Keep the zero test a select: left alone, the compiler sinks the whole polynomial into a branch
 	// on u != 0, which also keeps the three logarithms of a bounce from being scheduled together.
 	asm volatile("" : "+v"(r));
 	return u == 0.0f ? -DM_INF_F : r;
 }
-__device__ __forceinline__ float log_unit(float u) { return log_unit_biased<127>(u); }
-__device__ __forceinline__ float log_count(float c) { return log_unit_biased<159>(c); } // log(c / 2^32)
+__device__ __forceinline__ float log_unit(float u) { return log_unit_biased<127, true>(u); }
+__device__ __forceinline__ float log_count(float c) { return log_unit_biased<159, true>(c); } // log(c / 2^32)
 
 // dm_cosf restricted to finite x in [0, 8): detmath.h's range / NaN guard dropped.
 __device__ __forceinline__ float cos_2pi(float x) {
@@ -271,12 +311,27 @@ __device__ __forceinline__ float cos_2pi(float x) {
 	float s_res = dm_fmaf(r * z, p, r);
 	float c_res = dm_fmaf(z * z, p, dm_fmaf(-0.5f, z, 1.0f));
 	float res = odd ? s_res : c_res;
+#ifndef SRT_NO_COS_SIGN_BITS
+	// -res in quadrants 1 and 2: bit 1 of k + 1, moved to the sign position and xor-ed in (three integer ops and no compare /
+	// select pair; same bits as the select for every angle, srt_selftest_math out[2])
+	return dm_u2f(dm_f2u(res) ^ ((((uint32_t)k << 30) + 0x40000000u) & 0x80000000u));
+#else
 	return (((k + 1) >> 1) & 1) ? -res : res;
+#endif
 }
 
 // Box-Muller, theta drawn first (render.cl:150-154)
 __device__ __forceinline__ float random_normal(uint32_t &seed) {
-#ifndef SRT_NO_COUNT_FOLD
+#if !defined(SRT_NO_COUNT_FOLD) && !defined(SRT_NO_FAST_SQRT) && !defined(SRT_NO_RSQ_SQRT)
+	float theta = (6.28318548f * 2.3283064365386963e-10f) * random_count(seed); // = 6.28318548f * random_float, bit for bit
+	// -2 log u is -0 (u = 1), +inf (u = 0) or in [1.19e-7, 44.4] for every u random_float can return: the root by sqrt_rsq_zero_ok,
+	// and u = 0 (whose logarithm is left some finite number here) selected to sqrt(+inf) = +inf afterwards. Equal to the IEEE
+	// sqrt(-2 log u) for all 2^32 u: srt_selftest_math out[10].
+	const float cnt = random_count(seed);
+	float rho = sqrt_rsq_zero_ok(-2.0f * log_unit_biased<159, false>(cnt));
+	asm volatile("" : "+v"(rho)); // keep the zero test a select (see log_unit_biased)
+	rho = cnt == 0.0f ? DM_INF_F : rho;
+#elif !defined(SRT_NO_COUNT_FOLD)
 	float theta = (6.28318548f * 2.3283064365386963e-10f) * random_count(seed); // = 6.28318548f * random_float, bit for bit
 	// -2 log u is -0, +inf or in [1.19e-7, 44.4] for every u random_float can return: no small-argument guard
 	float rho = sqrt_core(-2.0f * log_count(random_count(seed)));
@@ -341,7 +396,9 @@ __device__ __forceinline__ void test_spheres(const Blk16 &s, f3 org, f3 dir, int
 		bq[i] = dot3(L, dir);
 		float c = dot3(L, L) - s.v[4 * i + 3];
 		disc[i] = bq[i] * bq[i] - c;
-#ifndef SRT_NO_FAST_SQRT
+#if !defined(SRT_NO_FAST_SQRT) && !defined(SRT_NO_RSQ_SQRT)
+		tiny = tiny || dm_fabs(disc[i]) < 0x1p-96f; // +-0 and 0 < |x| < 2^-96: one compare with |.| as a source modifier (a NaN is not "tiny")
+#elif !defined(SRT_NO_FAST_SQRT)
 		tiny = tiny || ((dm_f2u(disc[i]) & 0x7fffffffu) - 1u) < 0x0f7fffffu; // 0 < |x| < 2^-96
 #endif
 	}
@@ -351,7 +408,14 @@ __device__ __forceinline__ void test_spheres(const Blk16 &s, f3 org, f3 dir, int
 		for (int i = 0; i < N; i++) sq[i] = __builtin_sqrtf(disc[i]); // @rare
 	} else {
 #pragma unroll
+#ifndef SRT_NO_RSQ_SQRT
+		// disc is NaN, negative, +inf or normal and >= 2^-96 here. sqrt_rsq is the IEEE root on the last range and NaN on the others,
+		// IEEE sqrt is NaN on the first two and +inf for +inf -- and a discriminant of +inf never updates the hit either way: with
+		// sq = +inf, t = bq -+ inf is -inf then +inf (or NaN), and +inf < tmin is false; with sq = NaN, t is NaN and every compare false.
+		for (int i = 0; i < N; i++) sq[i] = sqrt_rsq(disc[i]);
+#else
 		for (int i = 0; i < N; i++) sq[i] = sqrt_core(disc[i]);
+#endif
 	}
 #else
 #pragma unroll
@@ -361,7 +425,13 @@ __device__ __forceinline__ void test_spheres(const Blk16 &s, f3 org, f3 dir, int
 	for (int i = 0; i < N; i++) {
 		float t = bq[i] - sq[i];
 		if (t < 0.0f) t = bq[i] + sq[i];
+#ifndef SRT_NO_RSQ_SQRT
+		// render.cl:187 `disc < 0 -> miss` needs no test of its own: the root of a negative discriminant is NaN (all three square
+		// roots above), so t is NaN and `t < tmin` is false; disc = -0 is not negative there either
+		bool hit = !(t < 0.0f);
+#else
 		bool hit = !(disc[i] < 0.0f) && !(t < 0.0f);
+#endif
 		if (hit && t < tmin) {
 			tmin = t;
 			best = idx0 + i;
@@ -1434,7 +1504,27 @@ __global__ __launch_bounds__(64, USE_BVH ? SRT_TRACE_WAVES_PER_SIMD_BVH : HAS_MO
 			if (got) {
 				SRT_REGION(CAMERA);
 				// ---- camera ray (render.cl:488,496-516) ----
+				// No per-lane integer division and no IEEE division sequence here: pixel, row and sample come from multiplications
+				// by host-made magic numbers (srt_magic_u31), the two quotients by the image size from div_by_rcp.
 				const auto &c = SRT_COLD(p);
+#ifndef SRT_NO_CAMERA_DIET
+				// off < nbs + SUB: one pixel further at most when a pixel has at least SUB samples in this batch, else off / nbs by a
+				// 16-bit reciprocal (exact below 256 for divisors below 128: the error off * (magic * nbs - 2^16) stays under 2^15)
+				const uint32_t dq = (nbs >= SUB) ? (off >= nbs ? 1u : 0u) : (off * c.nbs_magic16) >> 16;
+				const uint32_t q = qpix + dq; // owned pixels < 2^31 (checked by the host)
+				const uint32_t sample = c.first_sample + (off - dq * nbs);
+				const uint32_t lrow = (__umulhi(q, c.width_magic) + q) >> c.width_shift;
+				const int px = (int)(q - lrow * (uint32_t)width);
+				int py = (int)lrow;
+				if (c.world != 1) { // (wave-uniform) global y of packed local row (include/srt_abi.h srt_set_partition)
+					const uint32_t lb = (__umulhi(lrow, c.rpb_magic) + lrow) >> c.rpb_shift;
+					py = (int)((lb * (uint32_t)c.world + (uint32_t)c.rank) * (uint32_t)c.rows_per_block + (lrow - lb * (uint32_t)c.rows_per_block));
+				}
+				const uint32_t id = (uint32_t)px + (uint32_t)py * (uint32_t)width;
+				seed = (sample + id * (uint32_t)ns) * c.rd.time * 5304u;
+				float ndc_x = div_by_rcp((float)px + random_float(seed), c.f_width, c.inv_f_width);
+				float ndc_y = div_by_rcp((float)py + random_float(seed), c.f_height, c.inv_f_height);
+#else
 				const uint32_t dq = (nbs >= SUB) ? (off >= nbs ? 1u : 0u) : off / nbs;
 				const uint32_t q = qpix + dq; // owned pixels < 2^31 (checked by the host)
 				const uint32_t sample = c.first_sample + (off - dq * nbs);
@@ -1445,6 +1535,7 @@ __global__ __launch_bounds__(64, USE_BVH ? SRT_TRACE_WAVES_PER_SIMD_BVH : HAS_MO
 				seed = (sample + id * (uint32_t)ns) * c.rd.time * 5304u;
 				float ndc_x = ((float)px + random_float(seed)) / c.f_width;
 				float ndc_y = ((float)py + random_float(seed)) / c.f_height;
+#endif
 				float sx = ((2.f * ndc_x - 1.f) * c.rd.aspect_ratio) * c.rd.fov_scale;
 				float sy = (1.f - 2.f * ndc_y) * c.rd.fov_scale;
 				const f3 c0 = mk(c.rd.camera_to_world[0].x, c.rd.camera_to_world[0].y, c.rd.camera_to_world[0].z);
@@ -1647,8 +1738,11 @@ __global__ __launch_bounds__(256) void srt_resolve_kernel(const ResolveParams p)
 //   out[8] div3(a, b) != a / b          out[9] sum of bits of normalize(u - 0.5, 0.37 - u, (r & 0xffff) * 1e-3 - 30)
 //          (a, b: random mantissas and signs, exponents straddling the fast paths' guards,
 //           zero components mixed in)
-//   out[10] sqrt_core(-2 log_unit(u)) != IEEE sqrt, the one call site without a guard
+//   out[10] Box-Muller's rho as random_normal computes it (sqrt_rsq_zero_ok of -2 log of the raw count, u = 0 selected to +inf)
+//           != IEEE sqrt(-2 dm_logf(u))
 //   out[11] the 2^-32 scaling folded away: log_count(r) != log_unit(u), or K' * r != 6.28318548f * u
+//   out[12] sqrt_rsq(bits r) != __builtin_sqrtf for r a float in [2^-96, +inf) (every one of them at stride 1)
+//   out[13] div_by_rcp((px + u), W, 1 / W) != (px + u) / W over eight image sizes W (the host's 1 / W passed in)
 // ---------------------------------------------------------------------------------
 namespace {
 __device__ __forceinline__ bool same_float(float a, float b) { return (a != a && b != b) || dm_f2u(a) == dm_f2u(b); }
@@ -1666,9 +1760,12 @@ __device__ __forceinline__ float rand_float_exp(uint32_t &h, uint32_t lo, uint32
 __device__ __forceinline__ bool same_f3(f3 a, f3 b) { return same_float(a.x, b.x) && same_float(a.y, b.y) && same_float(a.z, b.z); }
 } // namespace
 
-__global__ __launch_bounds__(256) void srt_selftest_kernel(unsigned long long *out, uint32_t stride) {
+struct SelftestSizes {
+	float w[8], inv_w[8]; // image sizes and their reciprocals as the HOST rounds them
+};
+__global__ __launch_bounds__(256) void srt_selftest_kernel(unsigned long long *out, uint32_t stride, const SelftestSizes sz) {
 	unsigned long long bad_sqrt = 0, bad_log = 0, bad_cos = 0, s_log = 0, s_cos = 0, s_sqrt = 0, s_atan = 0, s_pow = 0;
-	unsigned long long bad_div = 0, bad_norm = 0, bad_rn = 0, bad_fold = 0;
+	unsigned long long bad_div = 0, bad_norm = 0, bad_rn = 0, bad_fold = 0, bad_rsq = 0, bad_cam = 0;
 	const unsigned long long total = (0x100000000ull + stride - 1) / stride;
 	for (unsigned long long i = blockIdx.x * (unsigned long long)blockDim.x + threadIdx.x; i < total;
 	     i += (unsigned long long)gridDim.x * blockDim.x) {
@@ -1689,7 +1786,21 @@ __global__ __launch_bounds__(256) void srt_selftest_kernel(unsigned long long *o
 		const float cnt = (float)r;
 		bad_fold += (same_float(log_count(cnt), log_unit(u)) && same_float((6.28318548f * 2.3283064365386963e-10f) * cnt, th)) ? 0 : 1;
 		const float arg = -2.0f * lg;
+#if !defined(SRT_NO_COUNT_FOLD) && !defined(SRT_NO_FAST_SQRT) && !defined(SRT_NO_RSQ_SQRT)
+		{
+			float rho = sqrt_rsq_zero_ok(-2.0f * log_unit_biased<159, false>(cnt));
+			rho = cnt == 0.0f ? DM_INF_F : rho;
+			bad_rn += same_float(rho, __builtin_sqrtf(arg)) ? 0 : 1;
+		}
+#else
 		bad_rn += same_float(sqrt_core(arg), __builtin_sqrtf(arg)) ? 0 : 1;
+#endif
+		if (r >= 0x0f800000u && r < 0x7f800000u) bad_rsq += same_float(sqrt_rsq(asbits), __builtin_sqrtf(asbits)) ? 0 : 1;
+		{
+			const float W = sz.w[r & 7u];
+			const float a = (float)((r >> 3) % (uint32_t)W) + u;
+			bad_cam += same_float(div_by_rcp(a, W, sz.inv_w[r & 7u]), a / W) ? 0 : 1;
+		}
 		// guards: numerators 2^-60 .. 2^50, denominator 2^-40 .. 2^40, squared length 2^-80 .. 2^80
 		uint32_t h = r ^ 0x9e3779b9u;
 		f3 a = mk(rand_float_exp(h, 127 - 64, 118), rand_float_exp(h, 127 - 64, 118), rand_float_exp(h, 127 - 64, 118));
@@ -1714,10 +1825,15 @@ __global__ __launch_bounds__(256) void srt_selftest_kernel(unsigned long long *o
 	atomicAdd(&out[9], bad_norm);
 	atomicAdd(&out[10], bad_rn);
 	atomicAdd(&out[11], bad_fold);
+	atomicAdd(&out[12], bad_rsq);
+	atomicAdd(&out[13], bad_cam);
 }
 
 void srt_launch_selftest(unsigned long long *out, uint32_t stride, void *stream) {
-	hipLaunchKernelGGL(srt_selftest_kernel, dim3(2048), dim3(256), 0, (hipStream_t)stream, out, stride);
+	SelftestSizes sz;
+	const float w[8] = {1920.f, 1080.f, 256.f, 3840.f, 2160.f, 960.f, 37.f, 16777216.f};
+	for (int i = 0; i < 8; i++) sz.w[i] = w[i], sz.inv_w[i] = 1.0f / w[i];
+	hipLaunchKernelGGL(srt_selftest_kernel, dim3(2048), dim3(256), 0, (hipStream_t)stream, out, stride, sz);
 }
 
 // ---------------------------------------------------------------------------------

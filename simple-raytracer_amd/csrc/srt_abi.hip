@@ -893,6 +893,10 @@ int srt_trace(srt_tracer *t, const srt_render_data *options) {
 	p.sky_h = t->sky_h;
 	p.f_width = (float)options->width;
 	p.f_height = (float)options->height;
+	p.inv_f_width = 1.0f / p.f_width; // IEEE quotients: the kernel's camera rays divide by multiplying with them (kernels.hip div_by_rcp)
+	p.inv_f_height = 1.0f / p.f_height;
+	srt_magic_u31(options->width > 0 ? (uint32_t)options->width : 1u, &p.width_magic, &p.width_shift);
+	srt_magic_u31(t->rows_per_block > 0 ? (uint32_t)t->rows_per_block : 1u, &p.rpb_magic, &p.rpb_shift);
 	p.f_sky_w = (float)t->sky_w;
 	p.f_sky_h = (float)t->sky_h;
 	p.sun_focus_int = dm_pow_small_int(p.sd.sun_focus);
@@ -1026,6 +1030,7 @@ int srt_trace(srt_tracer *t, const srt_render_data *options) {
 		const uint32_t s0 = b * batch;
 		const uint32_t nbs = (uint32_t)ns - s0 < batch ? (uint32_t)ns - s0 : batch;
 		p.batch_samples = nbs;
+		p.nbs_magic16 = nbs ? (65536u + nbs - 1u) / nbs : 0u;
 		p.first_sample = s0;
 		p.total_items = (unsigned long long)pixels * nbs;
 		// chunks per atomic: ~8 per resident wave for balance, whole sub-jobs (so that every sub-job starts
@@ -1309,23 +1314,23 @@ int srt_set_partition(srt_tracer *t, int rank, int world, int rows_per_block) {
 	return clear_canvas_impl(t);
 }
 
-int srt_selftest_math(srt_tracer *t, uint32_t stride, uint64_t out[12]) {
+int srt_selftest_math(srt_tracer *t, uint32_t stride, uint64_t out[16]) {
 	if (!t) return SRT_ERR_INVALID;
 	if (!out || stride == 0) return fail(t, SRT_ERR_INVALID, "srt_selftest_math: bad arguments");
 	SRT_HIP(t, hipSetDevice(t->device));
 	unsigned long long *d = nullptr;
-	SRT_HIP(t, hipMalloc(reinterpret_cast<void **>(&d), 12 * sizeof(unsigned long long)));
-	hipError_t e = hipMemsetAsync(d, 0, 12 * sizeof(unsigned long long), t->stream);
+	SRT_HIP(t, hipMalloc(reinterpret_cast<void **>(&d), 16 * sizeof(unsigned long long)));
+	hipError_t e = hipMemsetAsync(d, 0, 16 * sizeof(unsigned long long), t->stream);
 	if (e == hipSuccess) {
 		srt_launch_selftest(d, stride, t->stream);
 		e = hipGetLastError();
 	}
-	unsigned long long h[12] = {0};
+	unsigned long long h[16] = {0};
 	if (e == hipSuccess) e = hipMemcpyAsync(h, d, sizeof h, hipMemcpyDeviceToHost, t->stream);
 	if (e == hipSuccess) e = hipStreamSynchronize(t->stream);
 	(void)hipFree(d);
 	if (e != hipSuccess) return fail(t, SRT_ERR_HIP, std::string("srt_selftest_math: ") + hipGetErrorString(e));
-	for (int i = 0; i < 12; i++) out[i] = h[i];
+	for (int i = 0; i < 16; i++) out[i] = h[i];
 	return SRT_OK;
 }
 

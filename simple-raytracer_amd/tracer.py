@@ -318,7 +318,7 @@ class Tracer:
         return dict(zip(("nodes", "leaves", "depth", "build_us", "models_built", "models_reused", "models_refitted"), (int(v) for v in out)))
 
     def selftest_math(self, stride=1):
-        out = (C.c_uint64 * 12)()
+        out = (C.c_uint64 * 16)()
         self._check(self.lib.srt_selftest_math(self._h, stride, out))
         return [int(v) for v in out]
 

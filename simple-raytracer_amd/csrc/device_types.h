@@ -128,7 +128,7 @@ struct TraceParams {
 	uint32_t width_magic, width_shift; /* n / width = (mulhi(n, magic) + n) >> shift for n < 2^31 (srt_magic_u31) */
 	uint32_t rpb_magic, rpb_shift;     /* the same for rows_per_block */
 	uint32_t nbs_magic16;              /* n / batch_samples = (n * magic16) >> 16 for n < 256, when batch_samples < 128 (else unused) */
-	uint32_t _pad3;
+	int32_t all_materials_ok;          /* no shape with a negative material index: the closest shape is a hit without looking its material up (render.cl:404) */
 };
 
 /* n / d for 0 <= n < 2^31 as (mulhi(n, magic) + n) >> shift: Granlund & Montgomery's round-up method with shift = ceil(log2 d);

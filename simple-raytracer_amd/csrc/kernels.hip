@@ -57,6 +57,13 @@ enum SrtRegion {
 	R_COUNT
 };
 static_assert(R_COUNT <= SRT_REGION_MAX, "device_types.h SRT_REGION_MAX");
+// Scheduling diagnostics (iterations, SHADE phases, stragglers, early write-outs; srt_debug_counters out[5..7]) cost a few
+// scalar instructions and a vote per loop iteration: kept out of the product build, on in every development build.
+#if defined(SRT_DIAG) || defined(SRT_REGION_COUNT) || defined(SRT_PHASE_CLOCK)
+#define SRT_DIAG_ON 1
+#else
+#define SRT_DIAG_ON 0
+#endif
 #ifdef SRT_REGION_COUNT
 #define SRT_REGION(name) region_hit(region_ctr, R_##name)
 #define SRT_REGION_SLOT(name, slot) region_hit(region_ctr, R_##name##_0 + (slot)) // a stretch compiled once per block slot of a group (test_block)
@@ -77,6 +84,12 @@ __device__ __forceinline__ void region_hit(uint32_t *ctr, int r) {
 #endif
 
 namespace {
+
+// The lanes of the wave for which p holds, straight from the compare's SGPR pair. HIP's __ballot / __any take an int: the
+// bool is first materialised per lane (v_cndmask 0 / 1) and compared again (v_cmp_ne) -- two VALU instructions for each of the
+// ~10 votes of a loop iteration.
+__device__ __forceinline__ unsigned long long ballot64(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+__device__ __forceinline__ bool any64(bool p) { return __builtin_amdgcn_ballot_w64(p) != 0ull; }
 
 struct f3 {
 	float x, y, z;
@@ -156,6 +169,29 @@ __device__ __forceinline__ float sqrt_rsq_zero_ok(float x) {
 	const float s = x * y, h = 0.5f * y;
 	const float r = __builtin_fmaf(-s, s, x);
 	return __builtin_fmaf(r, h, s);
+}
+
+// sqrt_rsq / sqrt_rsq_zero_ok of N independent values, stage by stage. gfx950 wants one wait state between a transcendental
+// instruction and the first use of its result: left to itself the scheduler emits each root as one chain (v_rsq, s_nop, ...),
+// paying the s_nop -- an issue slot like any other -- N times. The barriers keep the N v_rsq together, which covers it.
+template <int N, bool ZERO_OK>
+__device__ __forceinline__ void sqrt_rsq_n(const float (&x)[N], float (&out)[N]) {
+	float y[N], s[N], h[N];
+#ifndef SRT_NO_SQRT_STAGES
+	__builtin_amdgcn_sched_barrier(0);
+#endif
+#pragma unroll
+	for (int i = 0; i < N; i++) y[i] = __builtin_amdgcn_rsqf(x[i]);
+#ifndef SRT_NO_SQRT_STAGES
+	__builtin_amdgcn_sched_barrier(0);
+#endif
+#pragma unroll
+	for (int i = 0; i < N; i++) {
+		if (ZERO_OK) y[i] = __builtin_amdgcn_fmed3f(y[i], 0.0f, 0x1p100f);
+		s[i] = x[i] * y[i], h[i] = 0.5f * y[i];
+	}
+#pragma unroll
+	for (int i = 0; i < N; i++) out[i] = __builtin_fmaf(__builtin_fmaf(-s[i], s[i], x[i]), h[i], s[i]);
 }
 
 // ---- IEEE division with the operand scaling factored out ------------------------------
@@ -342,6 +378,32 @@ __device__ __forceinline__ float random_normal(uint32_t &seed) {
 	return rho * cos_2pi(theta);
 }
 
+// Three of them (render.cl:156-158: x, y, z in that order, theta before rho each time), the three square roots side by side
+__device__ __forceinline__ f3 random_normal3(uint32_t &seed) {
+#if !defined(SRT_NO_COUNT_FOLD) && !defined(SRT_NO_FAST_SQRT) && !defined(SRT_NO_RSQ_SQRT) && !defined(SRT_NO_NORMAL3)
+	float th[3], cnt[3], arg[3], rho[3];
+#pragma unroll
+	for (int k = 0; k < 3; k++) {
+		th[k] = (6.28318548f * 2.3283064365386963e-10f) * random_count(seed);
+		cnt[k] = random_count(seed);
+	}
+#pragma unroll
+	for (int k = 0; k < 3; k++) arg[k] = -2.0f * log_unit_biased<159, false>(cnt[k]);
+	sqrt_rsq_n<3, true>(arg, rho);
+#pragma unroll
+	for (int k = 0; k < 3; k++) {
+		asm volatile("" : "+v"(rho[k])); // keep the zero test a select (see log_unit_biased)
+		rho[k] = cnt[k] == 0.0f ? DM_INF_F : rho[k];
+	}
+	return mk(rho[0] * cos_2pi(th[0]), rho[1] * cos_2pi(th[1]), rho[2] * cos_2pi(th[2]));
+#else
+	const float gx = random_normal(seed);
+	const float gy = random_normal(seed);
+	const float gz = random_normal(seed);
+	return mk(gx, gy, gz);
+#endif
+}
+
 // fp64 Schlick (render.cl:173-178); r0 = ((1-mu)/(1+mu))^2 is a per-material constant
 __device__ __forceinline__ float schlick(float r0, float cos_theta) {
 	double x = 1.0 - (double)cos_theta;
@@ -386,9 +448,66 @@ __device__ __forceinline__ uint32_t f2u(float f) { return __float_as_uint(f); }
 // run's last block with spheres of r*r = -inf, whose discriminant is -inf or NaN: never a hit). Straight-line:
 // the four tests are independent chains the scheduler can interleave, and the four square roots share ONE
 // small-argument guard (sqrt_ieee above) instead of a branch each. Updates the lane's closest hit in array order.
+// ---- closest-hit update with floats compared as unsigned integers --------------------------------------------------
+// render.cl keeps a hit when `!(t < 0) && t < tmin` (after `disc < 0` / `denom == 0` have returned a miss). For floats that
+// are not -0, "t >= 0 and t < tmin" is ONE unsigned compare of the bit patterns: non-negative floats (and +inf) order like
+// their bits, every negative float and every NaN has bits above +inf's, and tmin is never negative (it only ever takes a t
+// that passed this test; it starts at +inf). A miss reported through a NaN or an infinity needs no test of its own then:
+// the root of a negative discriminant is NaN, n.(p - o) / 0 is +-inf or NaN. -0 is the one value the two orders disagree on
+// (the reference accepts t = -0 and afterwards rejects every t >= +0 against tmin = -0): a wave that holds one -- as tmin, or
+// as a plane's quotient; a sphere's bq -+ sq cannot be -0 when sq > 0 -- runs the reference's own sequence instead.
+// Per sphere: sub, add, v_min_u32, compare, two selects (before: sub, add, compare, select, two compares, two selects and the
+// wait states of one more compare -> select pair).
+__device__ __forceinline__ bool is_neg_zero(float x) { return dm_f2u(x) == 0x80000000u; }
+__device__ __forceinline__ void take_if_closer(float t_key, int idx, float &tmin, int &best) {
+	if (dm_f2u(t_key) < dm_f2u(tmin)) {
+		tmin = t_key;
+		best = idx;
+	}
+}
+
+// render.cl:180-204 against N of the FOUR spheres held in a 64-byte block {cx, cy, cz, r*r} x 4 (the host fills a run's last
+// block with spheres of r*r = -inf, whose discriminant is -inf or NaN: never a hit; with N = 2 only the first two are
+// looked at). Straight-line: the tests are independent chains the scheduler can interleave. Updates the lane's closest hit
+// in array order.
 template <int N>
 __device__ __forceinline__ void test_spheres(const Blk16 &s, f3 org, f3 dir, int idx0, float &tmin, int &best) {
-	float bq[4], disc[4], sq[4];
+	float bq[4], disc[4];
+#if !defined(SRT_NO_FAST_SQRT) && !defined(SRT_NO_RSQ_SQRT)
+	bool slow = is_neg_zero(tmin);
+#pragma unroll
+	for (int i = 0; i < N; i++) {
+		f3 L = mk(s.v[4 * i] - org.x, s.v[4 * i + 1] - org.y, s.v[4 * i + 2] - org.z);
+		bq[i] = dot3(L, dir);
+		float c = dot3(L, L) - s.v[4 * i + 3];
+		disc[i] = bq[i] * bq[i] - c;
+		slow = slow || dm_fabs(disc[i]) < 0x1p-96f; // +-0 and 0 < |x| < 2^-96: one compare with |.| as a source modifier (a NaN is not "tiny")
+	}
+	if (__builtin_expect(any64(slow), 0)) { // (wave-uniform) the reference's sequence, IEEE square root
+#pragma unroll
+		for (int i = 0; i < N; i++) { // @rare
+			const float sq = __builtin_sqrtf(disc[i]); // @rare
+			float t = bq[i] - sq; // @rare
+			if (t < 0.0f) t = bq[i] + sq; // @rare
+			if (!(disc[i] < 0.0f) && !(t < 0.0f) && t < tmin) tmin = t, best = idx0 + i; // @rare
+		}
+	} else {
+		// disc is NaN, negative, +inf or normal and >= 2^-96 here. sqrt_rsq is the IEEE root on the last range and NaN on the others;
+		// IEEE sqrt is NaN on the first two and +inf for +inf -- and a discriminant of +inf never updates the hit either way: with
+		// sq = +inf, bq -+ inf is -inf then +inf (or NaN), and +inf < tmin is false; with sq = NaN every t is NaN.
+		float dd[N], sq[N];
+#pragma unroll
+		for (int i = 0; i < N; i++) dd[i] = disc[i];
+		sqrt_rsq_n<N, false>(dd, sq);
+#pragma unroll
+		for (int i = 0; i < N; i++) {
+			// the smaller root if it is not negative, else the larger: the smaller of the two bit patterns (bq - sq <= bq + sq)
+			const uint32_t k = min(dm_f2u(bq[i] - sq[i]), dm_f2u(bq[i] + sq[i]));
+			take_if_closer(dm_u2f(k), idx0 + i, tmin, best);
+		}
+	}
+#else
+	float sq[4];
 	bool tiny = false;
 #pragma unroll
 	for (int i = 0; i < N; i++) {
@@ -396,9 +515,7 @@ __device__ __forceinline__ void test_spheres(const Blk16 &s, f3 org, f3 dir, int
 		bq[i] = dot3(L, dir);
 		float c = dot3(L, L) - s.v[4 * i + 3];
 		disc[i] = bq[i] * bq[i] - c;
-#if !defined(SRT_NO_FAST_SQRT) && !defined(SRT_NO_RSQ_SQRT)
-		tiny = tiny || dm_fabs(disc[i]) < 0x1p-96f; // +-0 and 0 < |x| < 2^-96: one compare with |.| as a source modifier (a NaN is not "tiny")
-#elif !defined(SRT_NO_FAST_SQRT)
+#ifndef SRT_NO_FAST_SQRT
 		tiny = tiny || ((dm_f2u(disc[i]) & 0x7fffffffu) - 1u) < 0x0f7fffffu; // 0 < |x| < 2^-96
 #endif
 	}
@@ -408,14 +525,7 @@ __device__ __forceinline__ void test_spheres(const Blk16 &s, f3 org, f3 dir, int
 		for (int i = 0; i < N; i++) sq[i] = __builtin_sqrtf(disc[i]); // @rare
 	} else {
 #pragma unroll
-#ifndef SRT_NO_RSQ_SQRT
-		// disc is NaN, negative, +inf or normal and >= 2^-96 here. sqrt_rsq is the IEEE root on the last range and NaN on the others,
-		// IEEE sqrt is NaN on the first two and +inf for +inf -- and a discriminant of +inf never updates the hit either way: with
-		// sq = +inf, t = bq -+ inf is -inf then +inf (or NaN), and +inf < tmin is false; with sq = NaN, t is NaN and every compare false.
-		for (int i = 0; i < N; i++) sq[i] = sqrt_rsq(disc[i]);
-#else
 		for (int i = 0; i < N; i++) sq[i] = sqrt_core(disc[i]);
-#endif
 	}
 #else
 #pragma unroll
@@ -425,22 +535,18 @@ __device__ __forceinline__ void test_spheres(const Blk16 &s, f3 org, f3 dir, int
 	for (int i = 0; i < N; i++) {
 		float t = bq[i] - sq[i];
 		if (t < 0.0f) t = bq[i] + sq[i];
-#ifndef SRT_NO_RSQ_SQRT
-		// render.cl:187 `disc < 0 -> miss` needs no test of its own: the root of a negative discriminant is NaN (all three square
-		// roots above), so t is NaN and `t < tmin` is false; disc = -0 is not negative there either
-		bool hit = !(t < 0.0f);
-#else
 		bool hit = !(disc[i] < 0.0f) && !(t < 0.0f);
-#endif
 		if (hit && t < tmin) {
 			tmin = t;
 			best = idx0 + i;
 		}
 	}
+#endif
 }
 
 // render.cl:206-221 against TWO planes (one 64-byte block {p, 0, n, 0} x 2; a run's last block is filled with a
-// plane of normal 0: denom == 0, never a hit)
+// plane of normal 0: denom == 0, never a hit). (The unsigned-key update of take_if_closer does not pay here: a plane's
+// quotient can be -0, and testing for it costs what the key saves.)
 __device__ __forceinline__ void test_planes2(const Blk16 &b, uint32_t count, f3 org, f3 dir, int idx0, float &tmin, int &best) {
 #pragma unroll
 	for (int i = 0; i < 2; i++) {
@@ -879,8 +985,8 @@ __device__ __forceinline__ void resolve_ring(const TraceParams &p, const float *
 		c = c + m;
 		deliver<SUB>(st, stage, p.radiance, item, c, f0, f1 SRT_RC_ARG);
 	}
-	st.pend0 -= (uint32_t)__popcll(__ballot(f0));
-	st.pend1 -= (uint32_t)__popcll(__ballot(f1));
+	st.pend0 -= (uint32_t)__popcll(ballot64(f0));
+	st.pend1 -= (uint32_t)__popcll(ballot64(f1));
 	asm volatile("" ::: "memory");
 }
 } // namespace
@@ -918,6 +1024,7 @@ __global__ __launch_bounds__(64, USE_BVH ? SRT_TRACE_WAVES_PER_SIMD_BVH : HAS_MO
 	const int ns = p.rd.num_samples;
 	const int nb = p.rd.num_bounces;
 	const int n_shapes = p.sd.num_shapes;
+	const bool all_materials_ok = p.all_materials_ok != 0;
 	const BlockGroup *__restrict__ runs = p.runs;
 	const float *__restrict__ run_data = p.run_data;
 	const float *__restrict__ wtris = p.wtris;
@@ -1011,11 +1118,11 @@ __global__ __launch_bounds__(64, USE_BVH ? SRT_TRACE_WAVES_PER_SIMD_BVH : HAS_MO
 		SRT_REGION(LOOP_HEAD);
 		bool hit = false, missed = false, fin = false;
 		bool suspended = false; // SUSPEND: the lane's ray went to the scan queue in this iteration
-		w_iter++;
+		if (SRT_DIAG_ON) w_iter++;
 		SRT_CLK(6);
 		// ================= EXTEND: closest_intersection (render.cl:293-378), winner deferred =================
-		if (__any(active)) {
-			if (nb > 0) w_rays += (unsigned long long)__popcll(__ballot(active && !(SUSPEND && resumed))); // a resumed ray was counted when it set out
+		if (any64(active)) {
+			if (nb > 0) w_rays += (unsigned long long)__popcll(ballot64(active && !(SUSPEND && resumed))); // a resumed ray was counted when it set out
 			if (active) {
 				SRT_REGION(EXTEND_SETUP);
 				if (nb <= 0) { // render.cl:403: no bounce loop at all -> colour 0
@@ -1068,9 +1175,9 @@ __global__ __launch_bounds__(64, USE_BVH ? SRT_TRACE_WAVES_PER_SIMD_BVH : HAS_MO
 								// A big model. Few of a wave's rays enter its box at a time; scanning 10^5 triangles for them would
 								// leave the other lanes idle. Those rays wait in the scan queue -- with everything closest_intersection
 								// has found so far, so that they continue exactly where they left -- until a wave-full has gathered.
-								const unsigned long long want = __ballot(enter0);
+								const unsigned long long want = ballot64(enter0);
 								const uint32_t n_want = (uint32_t)__popcll(want);
-								const bool now = queue_dry || n_want >= (uint32_t)SRT_SCAN_NOW_MIN || sq_count + sq_pushed + n_want > SQ || __any(enter0 && resumed);
+								const bool now = queue_dry || n_want >= (uint32_t)SRT_SCAN_NOW_MIN || sq_count + sq_pushed + n_want > SQ || any64(enter0 && resumed);
 								if (!now) {
 									if (enter0) {
 										SRT_REGION(EXTEND_SUSPEND);
@@ -1092,7 +1199,7 @@ __global__ __launch_bounds__(64, USE_BVH ? SRT_TRACE_WAVES_PER_SIMD_BVH : HAS_MO
 							}
 							if (SUSPEND && !COUNT_TRIS && ((code >> 5) & 1u)) {
 								// per LANE (this is divergent code): summed over the wave at the end
-								const unsigned long long sb = __ballot(scan0);
+								const unsigned long long sb = ballot64(scan0);
 								if (scan0) {
 									w_scan_lanes++;
 									if ((sb & ((1ull << lane) - 1ull)) == 0ull) w_scans++; // the scan's first lane counts the scan
@@ -1162,9 +1269,13 @@ __global__ __launch_bounds__(64, USE_BVH ? SRT_TRACE_WAVES_PER_SIMD_BVH : HAS_MO
 					if (SUSPEND) resumed = false;
 					// a shape without a material counts as a miss (render.cl:404: material_index >= 0)
 					if (!SUSPEND || part) { // else: the ray waits in the scan queue, with all of its state
-						int material_index = -1;
-						if (best >= 0) material_index = USE_LDS ? (int)f2u(reinterpret_cast<const float *>(lds)[8 * best + 1]) : p.winners[best].material;
-						hit = material_index >= 0;
+						if (all_materials_ok) { // (wave-uniform) every shape of the scene has a material: no look-up, closest shape = hit
+							hit = best >= 0;
+						} else {
+							int material_index = -1;
+							if (best >= 0) material_index = USE_LDS ? (int)f2u(reinterpret_cast<const float *>(lds)[8 * best + 1]) : p.winners[best].material;
+							hit = material_index >= 0;
+						}
 						missed = !hit;
 						if (hit) org = org + dir * tmin; // rayhit->position (render.cl:312,343,362)
 					}
@@ -1173,34 +1284,46 @@ __global__ __launch_bounds__(64, USE_BVH ? SRT_TRACE_WAVES_PER_SIMD_BVH : HAS_MO
 			}
 		}
 
-		if (SUSPEND) sq_count += (uint32_t)__popcll(__ballot(suspended)); // wave-uniform again
+		if (SUSPEND) sq_count += (uint32_t)__popcll(ballot64(suspended)); // wave-uniform again
 		SRT_CLK(0);
 		// ---- escaped paths queue for the sky (wave-uniform control flow) ----
-		const unsigned long long mm = __ballot(missed);
+		const unsigned long long mm = ballot64(missed);
 		if (mm != 0ull) {
 			SRT_REGION(SKY_PUSH);
 			constexpr uint32_t RC = SRT_RING_CAP;
 			const uint32_t n_miss = (uint32_t)__popcll(mm);
 			const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mm, 0u));
-			uint32_t done = 0;
 			if (ring_count + n_miss > RC) { // does not fit: the sky lookups of what is queued first (ring_count lanes busy)
 				resolve_ring<SUB>(p, ring, ring_count, st, stage, lane SRT_RC_ARG);
 				ring_count = 0;
 			}
-			while (done < n_miss) { // one round unless more lanes escaped than the ring holds (RC < 64)
-				const uint32_t take = (RC - ring_count) < (n_miss - done) ? (RC - ring_count) : (n_miss - done);
-				if (missed && rank >= done && rank < done + take) {
-					const uint32_t e = ring_count + (rank - done);
+			if (RC == 64u) {
+				// an empty ring holds a whole wave's escapes: one round, no loop
+				if (missed) {
+					const uint32_t e = ring_count + rank;
 					ring[0 * RC + e] = dir.x, ring[1 * RC + e] = dir.y, ring[2 * RC + e] = dir.z;
 					ring[3 * RC + e] = mask.x, ring[4 * RC + e] = mask.y, ring[5 * RC + e] = mask.z;
 					ring[6 * RC + e] = color.x, ring[7 * RC + e] = color.y, ring[8 * RC + e] = color.z;
 					ring[9 * RC + e] = dm_u2f(item);
 				}
-				ring_count += take;
-				done += take;
-				if (done < n_miss) {
-					resolve_ring<SUB>(p, ring, ring_count, st, stage, lane SRT_RC_ARG);
-					ring_count = 0;
+				ring_count += n_miss;
+			} else {
+				uint32_t done = 0;
+				while (done < n_miss) { // more lanes may have escaped than the ring holds
+					const uint32_t take = (RC - ring_count) < (n_miss - done) ? (RC - ring_count) : (n_miss - done);
+					if (missed && rank >= done && rank < done + take) {
+						const uint32_t e = ring_count + (rank - done);
+						ring[0 * RC + e] = dir.x, ring[1 * RC + e] = dir.y, ring[2 * RC + e] = dir.z;
+						ring[3 * RC + e] = mask.x, ring[4 * RC + e] = mask.y, ring[5 * RC + e] = mask.z;
+						ring[6 * RC + e] = color.x, ring[7 * RC + e] = color.y, ring[8 * RC + e] = color.z;
+						ring[9 * RC + e] = dm_u2f(item);
+					}
+					ring_count += take;
+					done += take;
+					if (done < n_miss) {
+						resolve_ring<SUB>(p, ring, ring_count, st, stage, lane SRT_RC_ARG);
+						ring_count = 0;
+					}
 				}
 			}
 			w_sky += n_miss;
@@ -1208,7 +1331,7 @@ __global__ __launch_bounds__(64, USE_BVH ? SRT_TRACE_WAVES_PER_SIMD_BVH : HAS_MO
 
 		SRT_CLK(1);
 		// ================= SHADE or PARK =================
-		const unsigned long long hb = __ballot(hit);
+		const unsigned long long hb = ballot64(hit);
 		const uint32_t n_hit = (uint32_t)__popcll(hb);
 		const uint32_t n_ready = n_hit + hq_count;
 		if (n_ready >= (uint32_t)SRT_SHADE_MIN || n_ready > HQ || (queue_dry && n_ready > 0u)) {
@@ -1241,7 +1364,7 @@ __global__ __launch_bounds__(64, USE_BVH ? SRT_TRACE_WAVES_PER_SIMD_BVH : HAS_MO
 				hq_head = hq_head >= HQ ? hq_head - HQ : hq_head;
 				hq_count -= n_pop;
 			}
-			w_shade++;
+			if (SRT_DIAG_ON) w_shade++;
 			if (hit) {
 				SRT_REGION(SHADE_WINNER);
 				// ---- winner: normal, material (render.cl:311-312,337-343,361-362,372-375); org = hit position ----
@@ -1317,10 +1440,7 @@ __global__ __launch_bounds__(64, USE_BVH ? SRT_TRACE_WAVES_PER_SIMD_BVH : HAS_MO
 					} else {
 						SRT_REGION(SHADE_BOUNCE);
 						// cosine weighted direction: 6 draws (render.cl:421, 156-163)
-						float gx = random_normal(seed);
-						float gy = random_normal(seed);
-						float gz = random_normal(seed);
-						f3 rd_ = normalize3(mk(gx, gy, gz));
+						f3 rd_ = normalize3(random_normal3(seed));
 						f3 hemi = rd_ * dm_sign(dot3(nrm, rd_));
 						f3 random_dir = normalize3(nrm + hemi);
 						f3 reflected_dir = reflect3(dir, nrm);
@@ -1387,19 +1507,19 @@ __global__ __launch_bounds__(64, USE_BVH ? SRT_TRACE_WAVES_PER_SIMD_BVH : HAS_MO
 		}
 
 		// ---- paths that ended in this iteration hand in their radiance ----
-		if (__any(fin)) {
+		if (any64(fin)) {
 			bool f0 = false, f1 = false;
 			SRT_REGION(HANDIN);
 			if (fin) deliver<SUB>(st, stage, p.radiance, item, color, f0, f1 SRT_RC_ARG);
-			const uint32_t n0 = (uint32_t)__popcll(__ballot(f0)), n1 = (uint32_t)__popcll(__ballot(f1));
+			const uint32_t n0 = (uint32_t)__popcll(ballot64(f0)), n1 = (uint32_t)__popcll(ballot64(f1));
 			st.pend0 -= n0, st.pend1 -= n1;
-			w_orphans += (uint32_t)__popcll(__ballot(fin)) - n0 - n1;
+			if (SRT_DIAG_ON) w_orphans += (uint32_t)__popcll(ballot64(fin)) - n0 - n1;
 		}
 
 		SRT_CLK(4);
 		// ================= REFILL: free lanes take new camera rays =================
 		SRT_REGION(REFILL_HEAD);
-		unsigned long long freeb = __ballot(!active);
+		unsigned long long freeb = ballot64(!active);
 		uint32_t n_free = (uint32_t)__popcll(freeb);
 		if (SUSPEND && sq_count != 0u && n_free != 0u &&
 		    (queue_dry || (n_free >= (uint32_t)SRT_REFILL_MIN && sq_count >= (n_free < (uint32_t)SRT_SCAN_NOW_MIN ? n_free : (uint32_t)SRT_SCAN_NOW_MIN)))) {
@@ -1428,7 +1548,7 @@ __global__ __launch_bounds__(64, USE_BVH ? SRT_TRACE_WAVES_PER_SIMD_BVH : HAS_MO
 			}
 			asm volatile("" ::: "memory");
 			sq_count -= n_pop;
-			freeb = __ballot(!active);
+			freeb = ballot64(!active);
 			n_free = (uint32_t)__popcll(freeb);
 		}
 		if (!queue_dry && n_free >= (uint32_t)SRT_REFILL_MIN) {
@@ -1451,7 +1571,7 @@ __global__ __launch_bounds__(64, USE_BVH ? SRT_TRACE_WAVES_PER_SIMD_BVH : HAS_MO
 						// behind this one).
 						const uint32_t o_pend = o ? st.pend1 : st.pend0;
 						flush_stage(stage + o * SUB * 3u, p.radiance + 3ull * (o ? st.base1 : st.base0), o_total, lane);
-						if (o_pend != 0u) w_evict++;
+						if (SRT_DIAG_ON && o_pend != 0u) w_evict++;
 						if (o) st.total1 = 0u, st.pend1 = 0u;
 						else st.total0 = 0u, st.pend0 = 0u;
 					}
@@ -1552,7 +1672,7 @@ __global__ __launch_bounds__(64, USE_BVH ? SRT_TRACE_WAVES_PER_SIMD_BVH : HAS_MO
 
 		SRT_CLK(5);
 		SRT_REGION(LOOP_TAIL);
-		if (!__any(active) && hq_count == 0u && sq_count == 0u) {
+		if (!any64(active) && hq_count == 0u && sq_count == 0u) {
 			if (queue_dry) break;
 			// Bounded: a wave that spins here without ever getting work leaves with the watchdog counter set instead of hanging.
 			if (++idle_spins > (1u << 20)) {

@@ -849,6 +849,9 @@ static int update_scene_impl(srt_tracer *t, const srt_shape *shapes, size_t n_sh
 		for (const auto &pl : plan) next_cache.push_back(std::move(pl.first ? t->bvh_cache->entries[pl.second] : fresh[pl.second]));
 		t->bvh_cache->entries = std::move(next_cache);
 	}
+	t->all_materials_ok = true;
+	for (size_t i = 0; i < n_shapes; i++)
+		if (shapes[i].material < 0) t->all_materials_ok = false;
 	t->num_runs = (int)groups.size();
 	t->num_materials = n_materials;
 	t->scene_set = true;
@@ -897,6 +900,7 @@ int srt_trace(srt_tracer *t, const srt_render_data *options) {
 	p.inv_f_height = 1.0f / p.f_height;
 	srt_magic_u31(options->width > 0 ? (uint32_t)options->width : 1u, &p.width_magic, &p.width_shift);
 	srt_magic_u31(t->rows_per_block > 0 ? (uint32_t)t->rows_per_block : 1u, &p.rpb_magic, &p.rpb_shift);
+	p.all_materials_ok = t->scene_set && t->all_materials_ok ? 1 : 0;
 	p.f_sky_w = (float)t->sky_w;
 	p.f_sky_h = (float)t->sky_h;
 	p.sun_focus_int = dm_pow_small_int(p.sd.sun_focus);

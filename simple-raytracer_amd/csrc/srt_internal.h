@@ -80,6 +80,7 @@ struct srt_tracer {
 	int sky_w = 0, sky_h = 0;
 	srt_scene_data sd{};
 	int num_models = 0;
+	bool all_materials_ok = false; // no shape of the scene has a negative material index
 	uint64_t scan_tris = 0; // array scan: triangles of the models a ray can be made to scan (all of them), for the launch-length bound
 	bool scene_set = false;
 	bool count_tris = false;

@@ -278,7 +278,8 @@ int srt_pipeline_flush(srt_tracer *t, uint8_t *argb_out, long long *frame_delive
  * (must be 0); out[12] = mismatch count of the kernel's reciprocal-root square root against IEEE sqrt on
  * the floats in [2^-96, inf) (all of them at stride 1; must be 0); out[13] = mismatch count of the camera
  * rays' division by the image size through the host's reciprocal against IEEE `/` (must be 0);
- * out[14..15] = 0 (reserved). */
+ * out[14] = mismatch count of the kernel's branch-free sign() against detmath's on all bit patterns (must be 0);
+ * out[15] = 0 (reserved). */
 int srt_selftest_math(srt_tracer *t, uint32_t stride, uint64_t out[16]);
 
 /* Library / build identification, e.g. "srt-hip gfx950 parity fp-contract=off". */

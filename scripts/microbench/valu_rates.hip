@@ -36,15 +36,23 @@ void run(const char *name, int per_iter, uint32_t *out, uint64_t *cyc) {
 	for (int waves_per_simd : {1, 2, 4, 8}) {
 		// one CU-filling launch: 256 CUs x 4 SIMDs x waves
 		const int blocks = 256 * 4 * waves_per_simd;
+		hipEvent_t e0, e1;
+		hipEventCreate(&e0), hipEventCreate(&e1);
 		hipLaunchKernelGGL(k<OP>, dim3(blocks), dim3(64), 0, 0, out, cyc, 1u, 12345u);
+		hipEventRecord(e0, 0);
 		hipLaunchKernelGGL(k<OP>, dim3(blocks), dim3(64), 0, 0, out, cyc, 1u, 12345u);
+		hipEventRecord(e1, 0);
 		hipDeviceSynchronize();
+		float ms = 0.f;
+		hipEventElapsedTime(&ms, e0, e1);
+		// wall-clock view: wave-instructions per SIMD per nanosecond (at 2.4 GHz, 0.5 per cycle = 1.2 per ns is the VALU peak)
+		const double per_ns = (double)N * per_iter * waves_per_simd / (ms * 1e6);
 		uint64_t h[64];
 		hipMemcpy(h, cyc, sizeof h, hipMemcpyDeviceToHost);
 		double avg = 0;
 		for (int i = 0; i < 64; i++) avg += (double)h[i];
 		avg /= 64;
-		printf("%-16s waves/SIMD %d: %.2f cycles per instruction per wave  (%.2f per SIMD)\n", name, waves_per_simd, avg / N / per_iter, avg / N / per_iter / waves_per_simd);
+		printf("%-16s waves/SIMD %d: %.2f s_memtime ticks per instruction per wave  (%.2f per SIMD); wall %.3f ms = %.3f wave-instructions per SIMD per ns\n", name, waves_per_simd, avg / N / per_iter, avg / N / per_iter / waves_per_simd, ms, per_ns);
 	}
 }
 int main() {

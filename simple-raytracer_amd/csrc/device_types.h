@@ -39,7 +39,7 @@ struct WinnerRec {
 	int32_t material;
 	float vx, vy, vz, w;
 	uint32_t first_wtri;
-	uint32_t _pad;
+	float inv_w; /* spheres: 1.0f / radius as the host rounds it (an IEEE quotient) when 2^-40 <= |radius| <= 2^40, else 0 (kernels.hip div3_by_rcp) */
 };
 static_assert(sizeof(WinnerRec) == 32, "WinnerRec 32 B");
 
@@ -128,6 +128,8 @@ struct TraceParams {
 	uint32_t width_magic, width_shift; /* n / width = (mulhi(n, magic) + n) >> shift for n < 2^31 (srt_magic_u31) */
 	uint32_t rpb_magic, rpb_shift;     /* the same for rows_per_block */
 	uint32_t nbs_magic16;              /* n / batch_samples = (n * magic16) >> 16 for n < 256, when batch_samples < 128 (else unused) */
+	uint32_t _pad4;
+	int32_t unit_materials;            /* the device materials hold bernoulli() thresholds in place of metallic / specular / transmittance */
 	int32_t all_materials_ok;          /* no shape with a negative material index: the closest shape is a hit without looking its material up (render.cl:404) */
 };
 

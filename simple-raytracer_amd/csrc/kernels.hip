@@ -244,6 +244,18 @@ __device__ __forceinline__ f3 div3(f3 a, float b) {
 #endif
 	return a / b; // @rare (scripts/isa_phase_mix.py: behind a range guard, counted as never executed)
 }
+// a / b, component-wise, with y = the host's correctly rounded 1 / b, or 0 when b is outside [2^-40, 2^40] (or not a number): the
+// sphere normal (p - c) / r with the radius' reciprocal from the winner record. Inside div3's box for the numerators the two
+// residual steps of div_core give the IEEE quotient for y = RN(1 / b) (Markstein, see div_by_rcp) -- one transcendental and two
+// fmas fewer than refining v_rcp_f32; everything else takes the compiler's division.
+__device__ __forceinline__ f3 div3_by_rcp(f3 a, float b, float y) {
+#if !defined(SRT_NO_FAST_DIV) && !defined(SRT_NO_HOST_RCP)
+	if (__builtin_expect(div_num_ok(a) && y != 0.0f, 1)) return mk(div_core(a.x, b, y), div_core(a.y, b, y), div_core(a.z, b, y));
+	return a / b; // @rare
+#else
+	return div3(a, b);
+#endif
+}
 // the built-in normalize: a * rsqrt(dot(a, a)) with detmath.h's division-free rsqrt -- 15 plain instructions, no
 // transcendental, no guard (before: IEEE sqrt and three IEEE quotients behind a range check)
 __device__ __forceinline__ f3 normalize3(f3 a) {
@@ -255,6 +267,19 @@ __device__ __forceinline__ f3 mix3(f3 x, f3 y, float a) {
 }
 __device__ __forceinline__ f3 ld3(const srt_float3 &p) { return mk(p.x, p.y, p.z); }
 __device__ __forceinline__ f3 ld3(const float *p) { return mk(p[0], p[1], p[2]); }
+
+// The built-in sign (detmath.h dm_sign: 1, -1, the zero itself, 0 for a NaN) without branches: the sign bit over 1.0 where x is
+// less or greater than 0 (v_cmp_lg: false for +-0 and NaN), else x where it is a zero, else 0. Five plain instructions (the
+// generic form compiles to two nested exec-mask branches); equal to dm_sign on all 2^32 bit patterns (srt_selftest_math out[14]).
+__device__ __forceinline__ float sign_fast(float x) {
+#ifndef SRT_NO_SIGN_FAST
+	const float one = dm_u2f((dm_f2u(x) & 0x80000000u) | 0x3f800000u);
+	const float zero_or_x = __builtin_amdgcn_class(x, 0x60) ? x : 0.0f; // class mask: -0 | +0
+	return __builtin_islessgreater(x, 0.0f) ? one : zero_or_x;
+#else
+	return dm_sign(x);
+#endif
+}
 
 // column-major 4x4 times (v, w): ((m0*v.x + m1*v.y) + m2*v.z) + m3*w  (render.cl:114-120)
 __device__ __forceinline__ f3 mat_by_vec(const srt_float4 *m, f3 v, float w) {
@@ -276,15 +301,25 @@ __device__ __forceinline__ f3 reflect3(f3 v, f3 n) { return v - n * (2.0f * dot3
 // random_count = (float)r, random_float = random_count / 2^32. The scaling by 2^-32 is exact and
 // never underflows (the smallest non-zero count is 1), so it commutes with any later rounding:
 // users that can absorb it into a constant or an exponent take the count and save the multiply.
-__device__ __forceinline__ float random_count(uint32_t &seed) {
+__device__ __forceinline__ float random_float_fwd(uint32_t &seed);
+__device__ __forceinline__ uint32_t random_bits(uint32_t &seed) {
 	seed = seed * 747796405u + 2891336453u;
 	uint32_t r = ((seed >> ((seed >> 28) + 4u)) ^ seed) * 277803737u;
-	r = (r >> 22) ^ r;
-	return (float)r;
+	return (r >> 22) ^ r;
+}
+__device__ __forceinline__ float random_count(uint32_t &seed) { return (float)random_bits(seed); }
+// `probability > random_float(seed)` (render.cl:427-430) as an integer compare: random_float is a monotone function of the
+// generator's 32 output bits r, so {r : p > random_float} is a prefix [0, T) of them; T(p) comes with the material from the
+// host (srt_update_scene, found by bisection with the same int -> float conversion), the conversion and the scaling are not
+// executed. Only for scenes whose probabilities all have T < 2^32 (p <= 1 does); others keep the float compare (unit_materials).
+__device__ __forceinline__ bool bernoulli(float p_or_threshold, bool thresholds, uint32_t &seed) {
+	if (thresholds) return random_bits(seed) < dm_f2u(p_or_threshold);
+	return p_or_threshold > random_float_fwd(seed);
 }
 __device__ __forceinline__ float random_float(uint32_t &seed) {
 	return random_count(seed) * 2.3283064365386963e-10f; // exact: division by 2^32
 }
+__device__ __forceinline__ float random_float_fwd(uint32_t &seed) { return random_float(seed); }
 
 // dm_logf restricted to what random_float can return: 0 or a normal float in
 // [2^-32, 1]. Same operations on that domain as detmath.h's dm_logf (whose negative /
@@ -1025,6 +1060,7 @@ __global__ __launch_bounds__(64, USE_BVH ? SRT_TRACE_WAVES_PER_SIMD_BVH : HAS_MO
 	const int nb = p.rd.num_bounces;
 	const int n_shapes = p.sd.num_shapes;
 	const bool all_materials_ok = p.all_materials_ok != 0;
+	const bool unit_materials = p.unit_materials != 0; // the materials carry integer thresholds in place of their three probabilities (bernoulli)
 	const BlockGroup *__restrict__ runs = p.runs;
 	const float *__restrict__ run_data = p.run_data;
 	const float *__restrict__ wtris = p.wtris;
@@ -1042,6 +1078,15 @@ __global__ __launch_bounds__(64, USE_BVH ? SRT_TRACE_WAVES_PER_SIMD_BVH : HAS_MO
 			for (int i = threadIdx.x; i < 12 * p.num_runs; i += 64) dst[p.num_runs + i] = gd4[i];
 		}
 		__syncthreads();
+	}
+	// header of the shape group EXTEND tests next; group 0 to begin with (sphere / plane scenes read their shape blocks from LDS)
+	uint32_t gh_code = 0;
+	int gh_f0 = 0, gh_f1 = 0, gh_f2 = 0;
+	if (USE_LDS && !HAS_MODELS && p.num_runs > 0) {
+		const float4 hv = lds[2 * n_shapes + 4 * p.num_materials];
+		gh_code = (uint32_t)__builtin_amdgcn_readfirstlane((int)f2u(hv.x));
+		gh_f0 = __builtin_amdgcn_readfirstlane((int)f2u(hv.y)), gh_f1 = __builtin_amdgcn_readfirstlane((int)f2u(hv.z));
+		gh_f2 = __builtin_amdgcn_readfirstlane((int)f2u(hv.w));
 	}
 
 	// ---- work distribution: one work-item = one (pixel, sample) path -------------------
@@ -1111,6 +1156,7 @@ __global__ __launch_bounds__(64, USE_BVH ? SRT_TRACE_WAVES_PER_SIMD_BVH : HAS_MO
 	uint32_t w_scans = 0, w_scan_lanes = 0; // SUSPEND diagnostics, per lane: triangle scans of big models this lane led / took part in
 	uint32_t n_tri = 0, n_tri_u = 0;
 	uint32_t idle_spins = 0;
+	uint32_t n_active = 0; // wave-uniform: lanes with `active` set, as of the end of the last iteration
 
 	SRT_CLK_DECL;
 	SRT_REGION(PROLOGUE);
@@ -1121,8 +1167,11 @@ __global__ __launch_bounds__(64, USE_BVH ? SRT_TRACE_WAVES_PER_SIMD_BVH : HAS_MO
 		if (SRT_DIAG_ON) w_iter++;
 		SRT_CLK(6);
 		// ================= EXTEND: closest_intersection (render.cl:293-378), winner deferred =================
-		if (any64(active)) {
-			if (nb > 0) w_rays += (unsigned long long)__popcll(ballot64(active && !(SUSPEND && resumed))); // a resumed ray was counted when it set out
+		if (n_active != 0u) { // lanes that hold a ray (counted at the end of the previous iteration: no vote here)
+			if (nb > 0) {
+				if (SUSPEND) w_rays += (unsigned long long)__popcll(ballot64(active && !resumed)); // a resumed ray was counted when it set out
+				else w_rays += n_active;
+			}
 			if (active) {
 				SRT_REGION(EXTEND_SETUP);
 				if (nb <= 0) { // render.cl:403: no bounce loop at all -> colour 0
@@ -1236,10 +1285,11 @@ __global__ __launch_bounds__(64, USE_BVH ? SRT_TRACE_WAVES_PER_SIMD_BVH : HAS_MO
 							// round trip of the path below costs a wave ~750 cycles per segment, an LDS read a fraction of that.
 							const float4 *__restrict__ lgh = lds + 2 * n_shapes + 4 * p.num_materials;
 							const float4 *__restrict__ lb = lgh + n_groups + 12 * g;
-							const float4 hv = lgh[g];
-							const uint32_t lcode = (uint32_t)__builtin_amdgcn_readfirstlane((int)f2u(hv.x));
-							const int f0 = __builtin_amdgcn_readfirstlane((int)f2u(hv.y)), f1 = __builtin_amdgcn_readfirstlane((int)f2u(hv.z)),
-							          f2 = __builtin_amdgcn_readfirstlane((int)f2u(hv.w));
+							// The header of the group under test lives in scalar registers (gh_*): read BEHIND the previous group's tests, for
+							// the group that comes next -- and never again in a scene of one group (up to 12 spheres / 6 planes), whose
+							// first block's reads so start at once instead of behind a header read, a wait and four v_readfirstlane.
+							const uint32_t lcode = gh_code;
+							const int f0 = gh_f0, f1 = gh_f1, f2 = gh_f2;
 							auto ld_lds = [&](int k) {
 								Blk16 b;
 								const float4 q0 = lb[4 * k], q1 = lb[4 * k + 1], q2 = lb[4 * k + 2], q3 = lb[4 * k + 3];
@@ -1250,6 +1300,14 @@ __global__ __launch_bounds__(64, USE_BVH ? SRT_TRACE_WAVES_PER_SIMD_BVH : HAS_MO
 							test_block(ld_lds(0), lcode & 255u, f0, 0u, 0);
 							if ((lcode >> 8) & 255u) test_block(ld_lds(1), (lcode >> 8) & 255u, f1, 0u, 1);
 							if ((lcode >> 16) & 255u) test_block(ld_lds(2), (lcode >> 16) & 255u, f2, 0u, 2);
+							int ng = n_groups;
+							asm volatile("" : "+s"(ng)); // (not to be recognised as loop-invariant: unswitching would duplicate the whole loop)
+							if (ng > 1) {
+								const float4 hv = lgh[g + 1 < n_groups ? g + 1 : 0];
+								gh_code = (uint32_t)__builtin_amdgcn_readfirstlane((int)f2u(hv.x));
+								gh_f0 = __builtin_amdgcn_readfirstlane((int)f2u(hv.y)), gh_f1 = __builtin_amdgcn_readfirstlane((int)f2u(hv.z));
+								gh_f2 = __builtin_amdgcn_readfirstlane((int)f2u(hv.w));
+							}
 						} else if (!HAS_MODELS) {
 							const Blk16 b0 = ld_blk16(gd), b1 = ld_blk16(gd + 16), b2 = ld_blk16(gd + 32);
 #ifdef SRT_PHASE_CLOCK_LOADS
@@ -1370,7 +1428,7 @@ __global__ __launch_bounds__(64, USE_BVH ? SRT_TRACE_WAVES_PER_SIMD_BVH : HAS_MO
 				// ---- winner: normal, material (render.cl:311-312,337-343,361-362,372-375); org = hit position ----
 				int type, material_index;
 				f3 wv;
-				float ww;
+				float ww, winv;
 				uint32_t first_wtri;
 				if (USE_LDS) {
 					const float4 w0 = lds[2 * best], w1 = lds[2 * best + 1];
@@ -1379,6 +1437,7 @@ __global__ __launch_bounds__(64, USE_BVH ? SRT_TRACE_WAVES_PER_SIMD_BVH : HAS_MO
 					wv = mk(w0.z, w0.w, w1.x);
 					ww = w1.y;
 					first_wtri = f2u(w1.z);
+					winv = w1.w;
 				} else {
 					const WinnerRec *__restrict__ wr = p.winners + best;
 					type = wr->type;
@@ -1386,11 +1445,12 @@ __global__ __launch_bounds__(64, USE_BVH ? SRT_TRACE_WAVES_PER_SIMD_BVH : HAS_MO
 					wv = mk(wr->vx, wr->vy, wr->vz);
 					ww = wr->w;
 					first_wtri = wr->first_wtri;
+					winv = wr->inv_w;
 				}
 				const f3 pos = org;
 				f3 nrm = mk(0.f, 0.f, 0.f);
 				if (type == SRT_SHAPE_SPHERE) {
-					nrm = div3(pos - wv, ww);
+					nrm = div3_by_rcp(pos - wv, ww, winv);
 				} else if (type == SRT_SHAPE_PLANE) {
 					nrm = wv;
 				} else if (HAS_MODELS) {
@@ -1441,13 +1501,17 @@ __global__ __launch_bounds__(64, USE_BVH ? SRT_TRACE_WAVES_PER_SIMD_BVH : HAS_MO
 						SRT_REGION(SHADE_BOUNCE);
 						// cosine weighted direction: 6 draws (render.cl:421, 156-163)
 						f3 rd_ = normalize3(random_normal3(seed));
-						f3 hemi = rd_ * dm_sign(dot3(nrm, rd_));
+						f3 hemi = rd_ * sign_fast(dot3(nrm, rd_));
 						f3 random_dir = normalize3(nrm + hemi);
 						f3 reflected_dir = reflect3(dir, nrm);
-						bool is_metallic = metallic > random_float(seed);
-						bool is_specular = specular > random_float(seed);
+						// the three material draws (render.cl:427-430; nothing else draws in between)
+						bool is_metallic, is_specular, is_transparent;
+						if (unit_materials) { // (wave-uniform)
+							is_metallic = bernoulli(metallic, true, seed), is_specular = bernoulli(specular, true, seed), is_transparent = bernoulli(transmittance, true, seed);
+						} else {
+							is_metallic = bernoulli(metallic, false, seed), is_specular = bernoulli(specular, false, seed), is_transparent = bernoulli(transmittance, false, seed);
+						}
 						f3 rough_dir = mix3(random_dir, reflected_dir, smoothness);
-						bool is_transparent = transmittance > random_float(seed);
 						if (!is_transparent) {
 							SRT_REGION(SHADE_OPAQUE);
 							dir = mix3(random_dir, rough_dir, (is_metallic || is_specular) ? 1.0f : 0.0f);
@@ -1477,7 +1541,7 @@ __global__ __launch_bounds__(64, USE_BVH ? SRT_TRACE_WAVES_PER_SIMD_BVH : HAS_MO
 						}
 						SRT_REGION(SHADE_TAIL);
 						dir = normalize3(dir);
-						org = pos + (nrm * dm_sign(dot3(nrm, dir))) * 0.001f; // render.cl:462
+						org = pos + (nrm * sign_fast(dot3(nrm, dir))) * 0.001f; // render.cl:462
 						bounce++;
 						active = true;
 					}
@@ -1521,6 +1585,7 @@ __global__ __launch_bounds__(64, USE_BVH ? SRT_TRACE_WAVES_PER_SIMD_BVH : HAS_MO
 		SRT_REGION(REFILL_HEAD);
 		unsigned long long freeb = ballot64(!active);
 		uint32_t n_free = (uint32_t)__popcll(freeb);
+		n_active = 64u - n_free;
 		if (SUSPEND && sq_count != 0u && n_free != 0u &&
 		    (queue_dry || (n_free >= (uint32_t)SRT_REFILL_MIN && sq_count >= (n_free < (uint32_t)SRT_SCAN_NOW_MIN ? n_free : (uint32_t)SRT_SCAN_NOW_MIN)))) {
 			SRT_REGION(REFILL_SCANQ);
@@ -1548,6 +1613,7 @@ __global__ __launch_bounds__(64, USE_BVH ? SRT_TRACE_WAVES_PER_SIMD_BVH : HAS_MO
 			}
 			asm volatile("" ::: "memory");
 			sq_count -= n_pop;
+			n_active += n_pop;
 			freeb = ballot64(!active);
 			n_free = (uint32_t)__popcll(freeb);
 		}
@@ -1621,6 +1687,7 @@ __global__ __launch_bounds__(64, USE_BVH ? SRT_TRACE_WAVES_PER_SIMD_BVH : HAS_MO
 				else st.pend0 += take;
 				w_paths += take;
 			}
+			n_active += given; // every lane served holds a camera ray from here on
 			if (got) {
 				SRT_REGION(CAMERA);
 				// ---- camera ray (render.cl:488,496-516) ----
@@ -1672,7 +1739,7 @@ __global__ __launch_bounds__(64, USE_BVH ? SRT_TRACE_WAVES_PER_SIMD_BVH : HAS_MO
 
 		SRT_CLK(5);
 		SRT_REGION(LOOP_TAIL);
-		if (!any64(active) && hq_count == 0u && sq_count == 0u) {
+		if (n_active == 0u && hq_count == 0u && sq_count == 0u) {
 			if (queue_dry) break;
 			// Bounded: a wave that spins here without ever getting work leaves with the watchdog counter set instead of hanging.
 			if (++idle_spins > (1u << 20)) {
@@ -1863,6 +1930,7 @@ __global__ __launch_bounds__(256) void srt_resolve_kernel(const ResolveParams p)
 //   out[11] the 2^-32 scaling folded away: log_count(r) != log_unit(u), or K' * r != 6.28318548f * u
 //   out[12] sqrt_rsq(bits r) != __builtin_sqrtf for r a float in [2^-96, +inf) (every one of them at stride 1)
 //   out[13] div_by_rcp((px + u), W, 1 / W) != (px + u) / W over eight image sizes W (the host's 1 / W passed in)
+//   out[14] sign_fast(bits r) != dm_sign
 // ---------------------------------------------------------------------------------
 namespace {
 __device__ __forceinline__ bool same_float(float a, float b) { return (a != a && b != b) || dm_f2u(a) == dm_f2u(b); }
@@ -1885,7 +1953,7 @@ struct SelftestSizes {
 };
 __global__ __launch_bounds__(256) void srt_selftest_kernel(unsigned long long *out, uint32_t stride, const SelftestSizes sz) {
 	unsigned long long bad_sqrt = 0, bad_log = 0, bad_cos = 0, s_log = 0, s_cos = 0, s_sqrt = 0, s_atan = 0, s_pow = 0;
-	unsigned long long bad_div = 0, bad_norm = 0, bad_rn = 0, bad_fold = 0, bad_rsq = 0, bad_cam = 0;
+	unsigned long long bad_div = 0, bad_norm = 0, bad_rn = 0, bad_fold = 0, bad_rsq = 0, bad_cam = 0, bad_sign = 0;
 	const unsigned long long total = (0x100000000ull + stride - 1) / stride;
 	for (unsigned long long i = blockIdx.x * (unsigned long long)blockDim.x + threadIdx.x; i < total;
 	     i += (unsigned long long)gridDim.x * blockDim.x) {
@@ -1915,6 +1983,7 @@ __global__ __launch_bounds__(256) void srt_selftest_kernel(unsigned long long *o
 #else
 		bad_rn += same_float(sqrt_core(arg), __builtin_sqrtf(arg)) ? 0 : 1;
 #endif
+		bad_sign += same_float(sign_fast(asbits), dm_sign(asbits)) ? 0 : 1;
 		if (r >= 0x0f800000u && r < 0x7f800000u) bad_rsq += same_float(sqrt_rsq(asbits), __builtin_sqrtf(asbits)) ? 0 : 1;
 		{
 			const float W = sz.w[r & 7u];
@@ -1947,6 +2016,7 @@ __global__ __launch_bounds__(256) void srt_selftest_kernel(unsigned long long *o
 	atomicAdd(&out[11], bad_fold);
 	atomicAdd(&out[12], bad_rsq);
 	atomicAdd(&out[13], bad_cam);
+	atomicAdd(&out[14], bad_sign);
 }
 
 void srt_launch_selftest(unsigned long long *out, uint32_t stride, void *stream) {

@@ -661,6 +661,10 @@ static int update_scene_impl(srt_tracer *t, const srt_shape *shapes, size_t n_sh
 			const srt_sphere &sp = s.shape.sphere;
 			data.insert(data.end(), {sp.position.x, sp.position.y, sp.position.z, sp.radius * sp.radius}); // r*r as render.cl:187
 			wr.vx = sp.position.x, wr.vy = sp.position.y, wr.vz = sp.position.z, wr.w = sp.radius;
+			{
+				const float ar = fabsf(sp.radius);
+				wr.inv_w = (ar >= 0x1p-40f && ar <= 0x1p40f) ? 1.0f / sp.radius : 0.0f; // (a NaN radius fails both compares)
+			}
 		} else if (s.type == SRT_SHAPE_PLANE) {
 			const srt_plane &pl = s.shape.plane;
 			data.insert(data.end(), {pl.position.x, pl.position.y, pl.position.z, 0.0f, pl.normal.x, pl.normal.y, pl.normal.z, 0.0f});
@@ -807,7 +811,28 @@ static int update_scene_impl(srt_tracer *t, const srt_shape *shapes, size_t n_sh
 		float r0 = (float)((1.0 - (double)mu) / (1.0 + (double)mu));
 		return r0 * r0;
 	};
+	// bernoulli() thresholds (kernels.hip): T(p) = how many of the generator's 2^32 outputs r give p > (float)r * 2^-32 -- a prefix,
+	// the conversion is monotone. When every probability of the scene has T < 2^32 (p <= 1 does) the device table carries the
+	// thresholds' bits in place of metallic / specular / transmittance.
+	auto threshold = [](float pr) -> uint64_t {
+		uint64_t lo = 0, hi = (uint64_t)1 << 32; // first r in [lo, hi] for which !(pr > u(r)); hi = 2^32: none
+		while (lo < hi) {
+			const uint64_t mid = (lo + hi) >> 1;
+			const float u = (float)(uint32_t)mid * 2.3283064365386963e-10f;
+			if (pr > u) lo = mid + 1;
+			else hi = mid;
+		}
+		return lo;
+	};
+	bool unit_materials = true;
+	for (const auto &m : dev_mats)
+		if (threshold(m.metallic) >> 32 || threshold(m.specular) >> 32 || threshold(m.transmittance) >> 32) unit_materials = false;
+	t->unit_materials = unit_materials;
 	for (auto &m : dev_mats) {
+		if (unit_materials) {
+			const uint32_t tm = (uint32_t)threshold(m.metallic), ts = (uint32_t)threshold(m.specular), tt = (uint32_t)threshold(m.transmittance);
+			memcpy(&m.metallic, &tm, 4), memcpy(&m.specular, &ts, 4), memcpy(&m.transmittance, &tt, 4);
+		}
 		const float inv_ior = 1.0f / m.refraction_index;
 		m._pad[0] = inv_ior;
 		m._pad[1] = schlick_r0(inv_ior);
@@ -901,6 +926,7 @@ int srt_trace(srt_tracer *t, const srt_render_data *options) {
 	srt_magic_u31(options->width > 0 ? (uint32_t)options->width : 1u, &p.width_magic, &p.width_shift);
 	srt_magic_u31(t->rows_per_block > 0 ? (uint32_t)t->rows_per_block : 1u, &p.rpb_magic, &p.rpb_shift);
 	p.all_materials_ok = t->scene_set && t->all_materials_ok ? 1 : 0;
+	p.unit_materials = t->scene_set && t->unit_materials ? 1 : 0;
 	p.f_sky_w = (float)t->sky_w;
 	p.f_sky_h = (float)t->sky_h;
 	p.sun_focus_int = dm_pow_small_int(p.sd.sun_focus);

@@ -81,6 +81,7 @@ struct srt_tracer {
 	srt_scene_data sd{};
 	int num_models = 0;
 	bool all_materials_ok = false; // no shape of the scene has a negative material index
+	bool unit_materials = false;   // the device material table holds bernoulli() thresholds (srt_update_scene)
 	uint64_t scan_tris = 0; // array scan: triangles of the models a ray can be made to scan (all of them), for the launch-length bound
 	bool scene_set = false;
 	bool count_tris = false;

@@ -79,6 +79,25 @@ def classify(mn):
     return "int"
 
 
+# Issue cost of a VALU instruction relative to a full-rate one (v_add_f32 / v_mul_f32 / v_xor / v_mov ... = 1), from the saturated
+# throughput measured on an MI355X with 8 waves per SIMD (scripts/microbench/valu_rates2.hip, profiles/r03_valu_rates_saturated.txt):
+# compares, selects, conversions, min / max / med3, left shifts, bit-field ops, three-operand integer ops, integer multiplies and
+# fp64 run at 0.57 of that rate, the transcendental unit at 0.29.
+FULL_RATE = ("v_add_f32", "v_sub_f32", "v_subrev_f32", "v_mul_f32", "v_fma_f32", "v_fmac_f32", "v_fmaak_f32", "v_fmamk_f32", "v_mac_f32", "v_xor_b32", "v_and_b32",
+             "v_or_b32", "v_not_b32", "v_lshrrev_b32", "v_ashrrev_i32", "v_mov_b32", "v_add_u32", "v_sub_u32", "v_subrev_u32", "v_accvgpr")
+
+
+def valu_cost(mn):
+    base = re.sub(r"_(e32|e64|sdwa|dpp)$", "", mn)
+    if base.startswith(("v_rcp", "v_rsq", "v_sqrt", "v_log", "v_exp", "v_sin", "v_cos")):
+        return 3.43
+    if base.startswith("v_mad_u64") or base.startswith("v_mad_i64"):
+        return 3.5
+    if base in FULL_RATE:
+        return 1.0
+    return 1.75
+
+
 LLVM_BIN = Path("/opt/rocm/lib/llvm/bin")
 
 
@@ -290,6 +309,8 @@ def static_mix(kernel, flags, cache="/tmp/srt_phase_mix.hsaco"):
                 cur = res[i]
             r = cur or bb_region.get(k, "PROLOGUE")
             per_region[r][classify(mn)] += 1
+            if classify(mn) in VALU_CLASSES:
+                per_region[r]["valu_cost"] += valu_cost(mn)
             listing.append((addr, r, classify(mn), text, " < ".join(f"{fn.split('(')[0]}:{line}" for fn, _, line in stacks[i]), k))
     static_mix.listing = listing
     return {r: dict(c) for r, c in per_region.items()}
@@ -335,7 +356,7 @@ def main():
     for r, c in st.items():
         f = waves.get(r, alias.get(r, 0))
         n = static_mix.copies.get(r, 1)
-        ex = {k: c.get(k, 0) * f / n for k in CLASSES}
+        ex = {k: c.get(k, 0) * f / n for k in CLASSES + ["valu_cost"]}
         out_regions[r] = {"phase": PHASE_OF.get(r, "other"), "wave_executions": f, "inlined_copies": n, "lanes_per_execution": round(lanes.get(r, 0) / f, 2) if f else None,
                           "static": {k: c.get(k, 0) for k in CLASSES if c.get(k, 0)}, "executed": {k: v for k, v in ex.items() if v}}
         phases[PHASE_OF.get(r, "other")].update(ex)
@@ -350,6 +371,8 @@ def main():
                   "regions tagged RARE (slow paths behind range guards, the general pow) are counted as never executed",
         "per_phase_executed_wave_instructions": {p: {k: int(v) for k, v in c.items() if v} for p, c in phases.items()},
         "per_phase_valu": {p: int(sum(c[k] for k in VALU_CLASSES)) for p, c in phases.items()},
+        "per_phase_valu_cost_share": {p: round(c["valu_cost"] / max(sum(cc["valu_cost"] for cc in phases.values()), 1), 4) for p, c in phases.items()},
+        "valu_cost_note": "valu_cost = executed VALU instructions weighted by their measured issue cost (full-rate fp32 / logic / shift-right / integer add = 1, half-rate classes 1.75, transcendental 3.43; isa_phase_mix.py valu_cost)",
         "per_phase_valu_share": {p: round(sum(c[k] for k in VALU_CLASSES) / valu_total, 4) for p, c in phases.items()},
         "per_phase_valu_lane_slots_per_ray": {p: round(64 * sum(c[k] for k in VALU_CLASSES) / rays, 1) for p, c in phases.items()},
         "total_executed": {k: int(v) for k, v in total.items() if v},
@@ -374,7 +397,7 @@ def main():
     txt = json.dumps(res, indent=1)
     if a.out:
         Path(a.out).write_text(txt + "\n")
-    print(json.dumps({k: res[k] for k in ("per_phase_valu_share", "per_phase_valu_lane_slots_per_ray", "valu_class_share", "valu_lane_slots_per_ray", "pmc_check") if k in res}, indent=1))
+    print(json.dumps({k: res[k] for k in ("per_phase_valu_cost_share", "per_phase_valu_share", "per_phase_valu_lane_slots_per_ray", "valu_class_share", "valu_lane_slots_per_ray", "pmc_check") if k in res}, indent=1))
 
 
 if __name__ == "__main__":

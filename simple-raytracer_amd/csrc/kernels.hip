@@ -1172,10 +1172,14 @@ __global__ __launch_bounds__(64, USE_BVH ? SRT_TRACE_WAVES_PER_SIMD_BVH : HAS_MO
 				if (SUSPEND) w_rays += (unsigned long long)__popcll(ballot64(active && !resumed)); // a resumed ray was counted when it set out
 				else w_rays += n_active;
 			}
-			if (active) {
+			// Sphere / plane scenes: the tests run for all 64 lanes, the lanes without a ray compute on whatever they hold and are
+			// sorted out when hit / missed are set -- no exec-mask bookkeeping around the phase, and hit / missed come straight out
+			// of compares. (With models a lane without a ray must not scan or walk.)
+			constexpr bool MASKED = HAS_MODELS;
+			if (!MASKED || active) {
 				SRT_REGION(EXTEND_SETUP);
 				if (nb <= 0) { // render.cl:403: no bounce loop at all -> colour 0
-					fin = true;
+					fin = MASKED ? true : active;
 				} else {
 					if (!SUSPEND || !resumed) {
 						tmin = DM_INF_F;
@@ -1334,8 +1338,10 @@ __global__ __launch_bounds__(64, USE_BVH ? SRT_TRACE_WAVES_PER_SIMD_BVH : HAS_MO
 							if (best >= 0) material_index = USE_LDS ? (int)f2u(reinterpret_cast<const float *>(lds)[8 * best + 1]) : p.winners[best].material;
 							hit = material_index >= 0;
 						}
-						missed = !hit;
-						if (hit) org = org + dir * tmin; // rayhit->position (render.cl:312,343,362)
+						if (!MASKED) hit = hit && active;
+						missed = MASKED ? !hit : (!hit && active);
+						if (!MASKED) org = org + dir * tmin; // (a lane that hit nothing, or held no ray, has no further use for its origin)
+						else if (hit) org = org + dir * tmin; // rayhit->position (render.cl:312,343,362)
 					}
 				}
 				active = false;
@@ -1448,12 +1454,10 @@ __global__ __launch_bounds__(64, USE_BVH ? SRT_TRACE_WAVES_PER_SIMD_BVH : HAS_MO
 					winv = wr->inv_w;
 				}
 				const f3 pos = org;
-				f3 nrm = mk(0.f, 0.f, 0.f);
+				f3 nrm = wv; // a plane's normal as stored
 				if (type == SRT_SHAPE_SPHERE) {
 					nrm = div3_by_rcp(pos - wv, ww, winv);
-				} else if (type == SRT_SHAPE_PLANE) {
-					nrm = wv;
-				} else if (HAS_MODELS) {
+				} else if (HAS_MODELS && type != SRT_SHAPE_PLANE) {
 					SRT_REGION(SHADE_MESH_NORMAL);
 					const srt_model *__restrict__ m = &p.shapes[best].shape.model;
 					const float *__restrict__ w = USE_BVH ? p.bvh_blocks + (size_t)(best_tri >> 2) * 32u + (best_tri & 3u) * SRT_BVH_TRI_FLOATS
@@ -1495,9 +1499,13 @@ __global__ __launch_bounds__(64, USE_BVH ? SRT_TRACE_WAVES_PER_SIMD_BVH : HAS_MO
 					const float transmittance = m1.x, ior = m1.y;
 					const f3 mcolor = mk(mc.x, mc.y, mc.z);
 					color = color + (mask * mk(me.x, me.y, me.z)) * emission_strength; // render.cl:413
-					if (bounce == nb - 1) {                                             // render.cl:415-416
-						fin = true;
-					} else {
+					// render.cl:415-416: the last bounce only collects the emission. Lanes on their last bounce run the code below along
+					// with the others and drop what it computes (the wave pays for it either way; not masking them out saves the
+					// exec-mask bookkeeping and the copies of mask / direction the compiler keeps around such a branch) -- unless
+					// the whole wave is on its last bounce.
+					const bool last = bounce == nb - 1;
+					fin = last;
+					if (any64(!last)) {
 						SRT_REGION(SHADE_BOUNCE);
 						// cosine weighted direction: 6 draws (render.cl:421, 156-163)
 						f3 rd_ = normalize3(random_normal3(seed));
@@ -1543,7 +1551,7 @@ __global__ __launch_bounds__(64, USE_BVH ? SRT_TRACE_WAVES_PER_SIMD_BVH : HAS_MO
 						dir = normalize3(dir);
 						org = pos + (nrm * sign_fast(dot3(nrm, dir))) * 0.001f; // render.cl:462
 						bounce++;
-						active = true;
+						active = !last;
 					}
 				}
 			}

@@ -589,7 +589,13 @@ __device__ __forceinline__ void test_planes2(const Blk16 &b, uint32_t count, f3 
 		f3 n = mk(b.v[8 * i + 4], b.v[8 * i + 5], b.v[8 * i + 6]);
 		float denom = dot3(n, dir);
 		float t = dot3(n, mk(b.v[8 * i] - org.x, b.v[8 * i + 1] - org.y, b.v[8 * i + 2] - org.z)) / denom;
+		// render.cl:209 `denom == 0 -> miss` needs no test of its own: x / 0 is +-inf or NaN, and +inf or a NaN is never below
+		// tmin, -inf is below 0
+#ifndef SRT_PLANE_DENOM_TEST
+		bool hit = !(t < 0.0f);
+#else
 		bool hit = !(dm_fabs(denom) == 0.0f) && !(t < 0.0f);
+#endif
 		if (hit && t < tmin) {
 			tmin = t;
 			best = idx0 + i;

@@ -110,7 +110,17 @@ def self_launch(argv, n):
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
            "--master-port", str(port), str(Path(__file__).resolve())] + argv
-    return subprocess.run(cmd, env=env).returncode
+    # a wedged collective must end the run, not hang it: the children get a deadline and are killed as a group past it
+    limit = float(os.environ.get("SRT_BENCH_TIMEOUT_S", "1500"))
+    proc = subprocess.Popen(cmd, env=env, start_new_session=True)
+    try:
+        return proc.wait(timeout=limit)
+    except subprocess.TimeoutExpired:
+        import signal
+        os.killpg(proc.pid, signal.SIGKILL)
+        proc.wait()
+        print(f"bench.py: the {n}-rank run did not finish within {limit:.0f} s and was killed", file=sys.stderr)
+        return 124
 
 
 def cpu_baseline(name, sky, target_seconds=15.0, spp_override=0):
@@ -187,6 +197,57 @@ def cpu_baseline(name, sky, target_seconds=15.0, spp_override=0):
     }
 
 
+def kernels_hash():
+    """sha256 of the kernel source a measurement belongs to (profiles/traffic.json carries the one it was taken with)"""
+    import hashlib
+    return hashlib.sha256((ROOT / "simple-raytracer_amd" / "csrc" / "kernels.hip").read_bytes()).hexdigest()
+
+
+def measure_config(name, sky, accel, steps, warmup, device):
+    """One BASELINE config on one GPU through a handle of its own, outside the headline's timed region: ms per step (wall,
+    outputs resident), the trace kernel's own time (HIP events), Mray/s, and the VALU roofline fraction where W_ops is defined
+    (array-order scan: triangle counters from the instrumented kernel variant, one extra untimed dispatch)."""
+    builder, w, h, spp, nb, desc = WORKLOADS[name]
+    shapes, tris, mats = builder()
+    t = T.Tracer(w, h, device=device)
+    t.set_skybox(sky)
+    t.options = R.render_data(w, h, spp, nb, camera_to_world=S.default_camera(), time=12345)
+    t.scene_data = R.scene_data(len(shapes))
+    if accel == "bvh":
+        t.set_acceleration(T.ACCEL_BVH)
+    t.update_scene(shapes, tris, mats)
+    for _ in range(warmup):
+        t.clear_canvas(); t.trace(); t.resolve(1)
+    t.synchronize()
+    t.reset_counters()
+    kms = []
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        t.clear_canvas(); t.trace(); t.resolve(1)
+        kms.append(t.last_trace_kernel_ms())  # synchronises the stream
+    t.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    c = t.counters()
+    launches, overlapped = t.last_trace_launches()
+    per = {"rays": c["rays"] // steps, "paths": c["paths"] // steps, "sky": c["sky"] // steps, "tri_tests": 0, "tri_pass_u": 0}
+    has_models = bool((shapes["type"] == R.SHAPE_MODEL).any())
+    frac = None
+    if not has_models or accel != "bvh":
+        if has_models:
+            t.count_triangles(True); t.reset_counters(); t.clear_canvas(); t.trace(); t.synchronize()
+            ci = t.counters()
+            per["tri_tests"], per["tri_pass_u"] = ci["tri_tests"], ci["tri_pass_u"]
+            t.count_triangles(False)
+        frac = round(w_ops(per, shapes) / (float(np.mean(kms)) * 1e-3) / VALU_PEAK_LANE_OPS, 4)
+    out = {"workload": desc + (" [BVH, srt_set_acceleration]" if accel == "bvh" else ""), "steps": steps, "ms_per_step": round(dt * 1e3, 3),
+           "kernel_ms": round(float(np.mean(kms)), 3), "kernel_ms_is": "span of overlapping sample-batch launches" if overlapped else "sum of the launches' own durations",
+           "launches_per_step": launches, "mray_s": round(per["rays"] / dt / 1e6, 1), "rays_per_step": per["rays"], "frac": frac}
+    if accel == "bvh":
+        out["frac_note"] = "W_ops (SURVEY 8d) has no term for hierarchy steps: no roofline fraction for the BVH walk"
+    t.close()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -196,6 +257,7 @@ def main():
     ap.add_argument("--spp", type=int, default=0, help="override samples per pixel (development only; makes the line non-comparable)")
     ap.add_argument("--rows-per-block", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the other_configs section (the other BASELINE configs on one GPU, measured after the headline)")
     ap.add_argument("--accel", default="none", choices=["none", "bvh"],
                     help="bvh = opt-in acceleration structure for model shapes (srt_set_acceleration); the headline line uses none")
     ap.add_argument("--gather", default="lib", choices=["lib", "torch"],
@@ -264,25 +326,41 @@ def main():
     # the library's own collective (srt_comm_init / srt_gather): rank 0 makes the RCCL id, torch.distributed ships it
     gather_mode = "none" if not collect else ("host-staged gloo (rehearsal)" if rehearsal else "torch.distributed.gather")
     if collect and not rehearsal and args.gather == "lib":
-        try:
-            ids = [T.Tracer.comm_unique_id() if rank == 0 else None]
-            dist.broadcast_object_list(ids, src=0)
-            t.comm_init(ids[0], rank, world)
-            gather_mode = "srt_gather (ncclGather inside libsrt_hip.so)"
-        except Exception as e:  # keep the run alive on the torch path, and say so in the line
-            gather_mode = f"torch.distributed.gather (srt_comm_init failed: {e})"
-        flags = [gather_mode.startswith("srt_gather")]
-        dist.all_gather_object(allf := [None] * world, flags[0])
-        if not all(allf):
-            gather_mode = "torch.distributed.gather (srt_comm_init failed on some rank)"
+        # Every rank takes part in every collective below whatever fails locally: rank 0 ALWAYS broadcasts (the id, or None when it
+        # could not make one), every rank then reports whether it can go on, and the communicator (itself a collective) is only
+        # initialised when all of them can. A rank that fails alone must not leave the others waiting in a different collective.
+        ident, why = None, ""
+        if rank == 0:
+            try:
+                if os.environ.get("SRT_BENCH_FAIL_COMM_ID"):  # test hook: exercise the fallback leg
+                    raise RuntimeError("SRT_BENCH_FAIL_COMM_ID is set")
+                ident = T.Tracer.comm_unique_id()
+            except Exception as e:
+                why = f"srt_comm_unique_id failed: {e}"
+        ids = [ident]
+        dist.broadcast_object_list(ids, src=0)
+        can = ids[0] is not None and hasattr(t.lib, "srt_comm_init")
+        dist.all_gather_object(allc := [None] * world, bool(can))
+        if all(allc):
+            ok_here = True
+            try:
+                t.comm_init(ids[0], rank, world)
+            except Exception as e:
+                ok_here, why = False, f"srt_comm_init failed: {e}"
+            dist.all_gather_object(allf := [None] * world, ok_here)
+            gather_mode = "srt_gather (ncclGather inside libsrt_hip.so)" if all(allf) else f"torch.distributed.gather ({why or 'srt_comm_init failed on another rank'})"
+        else:
+            gather_mode = f"torch.distributed.gather ({why or 'no RCCL id from rank 0'})"
     use_lib_gather = gather_mode.startswith("srt_gather")
 
-    trace_ms, resolve_ms, kernel_only_ms = [], [], []
+    trace_ms, resolve_ms, kernel_only_ms, gather_ms = [], [], [], []
+    g_ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) if collect else None
 
     def step(record):
         t.clear_canvas()
         t.trace()
         if collect:
+            g_ev[0].record(stream)
             if rehearsal:
                 host = canvas_t.cpu()
                 bufs = [torch.empty_like(host) for _ in range(world)] if rank == 0 else None
@@ -300,6 +378,7 @@ def main():
                 full = torch.cat(gather_bufs, dim=0).index_select(0, unperm)
                 t.resolve_external(full.data_ptr(), w * h, 1, argb_t.data_ptr())
                 step.full = full
+            g_ev[1].record(stream)  # gather + unpermute + (rank 0) resolve of the gathered frame
         elif rank == 0:
             t.resolve_external(canvas_t.data_ptr(), w * h, 1, argb_t.data_ptr())
         if record:
@@ -308,6 +387,9 @@ def main():
             resolve_ms.append(b)
             kernel_only_ms.append(t.last_trace_kernel_ms())
             step.launches = t.last_trace_launches()
+            if collect:
+                g_ev[1].synchronize()
+                gather_ms.append(g_ev[0].elapsed_time(g_ev[1]))
 
     def fence():
         torch.cuda.synchronize(dev)
@@ -331,12 +413,14 @@ def main():
 
     c = t.counters()
     red_dev = torch.device("cpu") if rehearsal else dev
-    stats = torch.tensor([elapsed, float(np.mean(kernel_only_ms)) if kernel_only_ms else 0.0], dtype=torch.float64, device=red_dev)
+    k_mean = float(np.mean(kernel_only_ms)) if kernel_only_ms else 0.0
+    g_mean = float(np.mean(gather_ms)) if gather_ms else 0.0
+    stats = torch.tensor([elapsed, k_mean, -k_mean, g_mean], dtype=torch.float64, device=red_dev)
     cnt = torch.tensor([c["rays"], c["paths"], c["sky"], c["nan_pixels"]], dtype=torch.int64, device=red_dev)
     if collect:
         dist.all_reduce(stats, op=dist.ReduceOp.MAX)
         dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
-    elapsed_max, trace_ms_max = float(stats[0]), float(stats[1])
+    elapsed_max, trace_ms_max, trace_ms_min, gather_ms_max = float(stats[0]), float(stats[1]), -float(stats[2]), float(stats[3])
     rays, paths, nsky, nan_px = (int(v) for v in cnt.tolist())
 
     check = None
@@ -370,11 +454,15 @@ def main():
         nbytes_alg = w_bytes_survey(per, w * h, scene_bytes, sky.nbytes)
         kt = trace_ms_max * 1e-3 if trace_ms_max > 0 else elapsed_max / steps
         achieved = ops / kt / 1e12 / world  # per-GPU rate: each GPU ran 1/world of the ops in kt
+        # HBM bytes per launch from the PMC passes of scripts/pmc_traffic.sh -- only when that file was measured on THIS kernel source
+        # (it carries the sha256 of csrc/kernels.hip); a stale measurement reads as null
         traffic = None
         tf = ROOT / "profiles" / "traffic.json"
         if tf.exists() and world == 1:  # measured for the whole frame on one GPU
             try:
-                traffic = json.loads(tf.read_text()).get(args.workload if not args.spp else "", {}).get("hbm_bytes_per_launch")
+                tj = json.loads(tf.read_text())
+                if tj.get("kernels_hip_sha256") == kernels_hash():
+                    traffic = tj.get(args.workload if not args.spp else "", {}).get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
         line = {
@@ -396,7 +484,7 @@ def main():
                        **({"accel": {"kind": "bvh", **t.acceleration_info(), "note": "triangle counters are the BVH walk's leaf tests; node box tests are not in W_ops"}} if args.accel == "bvh" else {})},
             "mpath_per_s": round(paths / elapsed_max / 1e6, 2),
             "rays_per_step": per["rays"], "paths_per_step": per["paths"], "nan_pixels": nan_px,
-            "kernel_ms": {"srt_trace_kernel": round(trace_ms_max, 3),
+            "kernel_ms": {("trace_launch_span" if step.launches[1] else "srt_trace_kernel"): round(trace_ms_max, 3),
                           "trace_plus_ordered_reduce": round(float(np.mean(trace_ms)) if trace_ms else 0.0, 3),
                           "resolve": round(float(np.mean(resolve_ms)) if resolve_ms else 0.0, 4)},
             "roofline": {
@@ -413,6 +501,10 @@ def main():
                         "note": "design bytes = algorithmic bytes (SURVEY.md 8d W_bytes) + 24 B per path of radiance written by the trace kernel and read by the ordered reduction"},
             },
         }
+        if world > 1:
+            line["per_rank"] = {"trace_kernel_ms_min": round(trace_ms_min, 3), "trace_kernel_ms_max": round(trace_ms_max, 3),
+                                "gather_ms": round(gather_ms_max, 3),
+                                "gather_ms_is": "max over ranks of: collective + unpermute + (rank 0) resolve of the gathered frame, on the launch stream, behind the rank's trace"}
         ok = True
         if check is not None:
             line["gathered_equals_single_gpu"] = check
@@ -427,12 +519,28 @@ def main():
             cb["gpu_rows_checked"] = int(sum(y1 - y0 for y0, y1 in port_rows))
             line["cpu_baseline"] = cb
             ok = ok and cb["gpu_equals_port"] and cb.get("reference_equals_port", True)
+        if world == 1 and args.workload == "spheres_1080p_1024spp" and not args.spp and not args.no_other_configs:
+            # the other BASELINE configs on this GPU, after the headline's timed region (handles of their own; headline fields unchanged)
+            t.close()
+            t = None
+            del canvas_t
+            torch.cuda.empty_cache()
+            others = []
+            for name, accel, k, wu in (("spheres_256_16spp", "none", 20, 2), ("meshes_1080p_512spp", "none", 3, 1), ("meshes_1080p_512spp", "bvh", 3, 1),
+                                       ("mesh100k_1080p_256spp", "bvh", 3, 1), ("mesh100k_1080p_256spp", "none", 1, 0), ("spheres_4k_4096spp", "none", 1, 1)):  # (configs[3]: one warm-up step, which also allocates its 2 x 48 GB of radiance)
+                try:
+                    others.append(measure_config(name, sky, accel, k, wu, local_rank))
+                except Exception as e:  # the headline line is still written
+                    others.append({"workload": name, "accel": accel, "error": str(e)})
+            line["other_configs"] = others
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(line) + "\n").encode())
         if not ok:
-            t.close()
+            if t is not None:
+                t.close()
             raise SystemExit("bench.py: the timed canvas differs from its checker (see gpu_equals_port / gathered_equals_single_gpu in the line above)")
-    t.close()
+    if t is not None:
+        t.close()
     if collect:
         dist.destroy_process_group()
 

@@ -31,6 +31,12 @@
 #ifndef SRT_DETMATH_H
 #define SRT_DETMATH_H
 
+/* The numerics are FROZEN at this revision: tests/golden/*.npz carry it (make_golden.py stamps it), tests/golden/MANIFEST.json
+ * records it next to the files' hashes and this header's, and tests/test_golden_manifest.py fails when any of them moves.
+ * Changing a built-in below means: bump the number, regenerate the goldens, re-run tests/test_oracle_statistics.py with
+ * /root/reference present and commit its report under profiles/ (DESIGN.md "Numerics"). */
+#define DM_REVISION 2
+
 #include <stdint.h>
 
 #if defined(__HIPCC__)

@@ -980,7 +980,7 @@ int srt_trace(srt_tracer *t, const srt_render_data *options) {
 	// allocate; if the device cannot give that much right now, fall back to smaller batches
 	while (batch) {
 		const size_t buffers = SRT_OVERLAP_BATCHES && batch < (uint32_t)ns ? 2 : 1;
-		hipError_t e = t->radiance.reserve(buffers * (pixels * (size_t)batch * 3 + 4));
+		hipError_t e = t->radiance.reserve(buffers * (((pixels * (size_t)batch * 3 + 4) + 3) & ~(size_t)3)); // each buffer a whole number of 16-byte units
 		if (e == hipSuccess) break;
 		(void)hipGetLastError(); // clear the sticky out-of-memory state
 		if (e != hipErrorOutOfMemory || batch == 1)
@@ -1037,7 +1037,7 @@ int srt_trace(srt_tracer *t, const srt_render_data *options) {
 	// reduction that last read its buffer.
 	const bool overlap = SRT_OVERLAP_BATCHES && n_batches > 1;
 	t->batches_overlapped = overlap;
-	const size_t radiance_stride = pixels * (size_t)batch * 3 + 4; // floats per buffer
+	const size_t radiance_stride = ((pixels * (size_t)batch * 3 + 4) + 3) & ~(size_t)3; // floats per buffer: a multiple of 4, so that the second buffer's float4 stores stay 16-byte aligned for any pixel count and batch size
 	if (overlap) {
 		for (int k = 0; k < 2; k++) {
 			if (!t->batch_stream[k]) SRT_HIP(t, hipStreamCreateWithFlags(&t->batch_stream[k], hipStreamNonBlocking));

@@ -320,6 +320,10 @@ int srt_group_create(int width, int height, int n_devices, const int *devices, i
 	for (int i = 0; i < n_devices; i++) {
 		SrtCollect *c = collect_of(g->t[i]);
 		if (!c) {
+			// the communicators not yet attached to a handle (i and above) belong to nobody: destroy them here, the attached ones
+			// go with their handles in srt_group_destroy
+			for (int k = i; k < n_devices; k++)
+				if (comms[k]) (void)rccl().CommDestroy(comms[k]);
 			srt_group_destroy(g);
 			return fail(nullptr, SRT_ERR_INVALID, "out of host memory");
 		}

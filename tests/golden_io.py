@@ -16,7 +16,7 @@ def _rec(raw, dtype, scalar=False):
 
 def load_cases():
     z = np.load(GOLDEN / "cases.npz")
-    names = sorted({k.split("/")[0] for k in z.files})
+    names = sorted({k.split("/")[0] for k in z.files if "/" in k})  # (the file also carries `detmath_revision`)
     out = {}
     for n in names:
         g = lambda key: z[f"{n}/{key}"]
@@ -31,9 +31,14 @@ def load_cases():
 
 def load_kats():
     z = np.load(GOLDEN / "kats.npz")
-    return {k: z[k] for k in z.files}
+    return {k: z[k] for k in z.files if k != "detmath_revision"}
 
 
 def load_sky_probe():
     z = np.load(GOLDEN / "sky_probe.npz")
     return int(z["checksum"][0]), z["probe"]
+
+
+def golden_revisions():
+    """detmath revision stamped into each fixture file by make_golden.py"""
+    return {n: int(np.load(GOLDEN / f"{n}.npz")["detmath_revision"][0]) for n in ("cases", "kats")}

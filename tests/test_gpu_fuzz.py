@@ -24,7 +24,9 @@ def random_scene(rng, hostile):
                              emission=rng.uniform(0, 1, 3), emission_strength=rng.choice([0, 0, rng.uniform(0, 5)]))
     if hostile:
         m = mats[rng.randint(n_mats)]
-        kind = rng.randint(6)
+        kind = rng.randint(8)
+        if kind == 6: m["metallic"] = rng.choice([1.5, -0.2, np.inf])      # probabilities outside [0, 1]: the integer-threshold
+        if kind == 7: m["transmittance"], m["specular"] = 2.0, -1.0        # draws (kernels.hip bernoulli) fall back to floats
         if kind == 0: m["refraction_index"] = 0.0
         if kind == 1: m["color"] = (np.nan, 1.0, np.inf)
         if kind == 2: m["smoothness"] = rng.choice([-3.0, 7.0, np.nan])

@@ -238,6 +238,23 @@ def test_sample_batches_are_invisible(name, T, sky):
     t.close()
 
 
+def test_odd_frame_in_tiny_batches(T, sky, oracle):
+    """A frame whose pixel count is not a multiple of 4 (37 x 41) traced in batches of one and three samples: the two radiance
+    buffers of overlapping batches must both start on 16-byte boundaries, and the magic-number pixel / row
+    arithmetic of the camera rays must agree with the oracle's divisions for an odd width."""
+    g = CASES["spheres"]
+    rd = g["rd"].copy()
+    rd["width"], rd["height"], rd["num_samples"] = 37, 41, 7
+    rd["aspect_ratio"] = np.float32(37 / 41)
+    want = oracle.render(rd, g["sd"], g["shapes"], g["tris"], g["mats"], sky)
+    for budget in (1, 37 * 41 * 12 * 3):
+        t = make_tracer(T, g, sky, rd)
+        t.set_radiance_budget(budget)
+        t.trace()
+        assert bits_equal(t.read_canvas(), want), f"budget {budget}"
+        t.close()
+
+
 def test_zero_and_negative_sample_counts(T, sky, oracle):
     """num_samples = 0 -> colour 0/0 = NaN added to every pixel; negative -> -0 (render.cl:520)."""
     g = CASES["spheres"]

@@ -46,7 +46,7 @@
 	X(PROLOGUE) X(LOOP_HEAD) X(EXTEND_SETUP) X(EXTEND_GROUP) X(EXTEND_SUSPEND)                                                       \
 	X(EXTEND_SPHERES2_0) X(EXTEND_SPHERES2_1) X(EXTEND_SPHERES2_2) X(EXTEND_SPHERES4_0) X(EXTEND_SPHERES4_1) X(EXTEND_SPHERES4_2)   \
 	X(EXTEND_PLANES_0) X(EXTEND_PLANES_1) X(EXTEND_PLANES_2) X(EXTEND_MODEL_0) X(EXTEND_MODEL_1) X(EXTEND_MODEL_2)                   \
-	X(EXTEND_TRI_LOOP) X(EXTEND_BVH_STEP) X(EXTEND_FINISH) X(SKY_PUSH) X(SKY_RESOLVE) X(SHADE_HEAD) X(SHADE_POP) X(SHADE_WINNER)   \
+	X(EXTEND_TRI_LOOP) X(EXTEND_TRI_EXACT) X(EXTEND_BVH_STEP) X(EXTEND_FINISH) X(SKY_PUSH) X(SKY_RESOLVE) X(SHADE_HEAD) X(SHADE_POP) X(SHADE_WINNER)   \
 	X(SHADE_MESH_NORMAL) X(SHADE_MATERIAL) X(SHADE_BOUNCE) X(SHADE_OPAQUE) X(SHADE_GLASS) X(SHADE_REFRACT) X(SHADE_TAIL) X(PARK)     \
 	X(HANDIN) X(HANDIN_ORPHAN) X(REFILL_HEAD) X(REFILL_SCANQ) X(REFILL_LOOP) X(REFILL_OPEN) X(REFILL_FLUSH) X(REFILL_CURSOR)         \
 	X(REFILL_TAKE) X(CAMERA) X(LOOP_TAIL) X(EPILOGUE)
@@ -634,7 +634,7 @@ __device__ __forceinline__ bool test_aabb(float lx, float ly, float lz, float hx
 // Returns true when the reference accepts the triangle; t is then its hit distance.
 template <bool COUNT_TRIS>
 __device__ __forceinline__ bool moller_trumbore(float v0x, float v0y, float v0z, float e1x, float e1y, float e1z, float e2x, float e2y,
-                                                float e2z, f3 org, f3 dir, bool counted, float &t, uint32_t &n_tri_u) {
+                                                float e2z, f3 org, f3 dir, bool counted, float &t, uint32_t &n_tri_u SRT_RC_PARAM) {
 	f3 e1 = mk(e1x, e1y, e1z), e2 = mk(e2x, e2y, e2z);
 	f3 h = cross3(dir, e2);
 	float a = dot3(e1, h);
@@ -644,6 +644,7 @@ __device__ __forceinline__ bool moller_trumbore(float v0x, float v0y, float v0z,
 	bool reject = (a == 0.0f) || (ash > aa * 1.001f) || ((sh * a < 0.0f) && (ash >= aa * 0.001f));
 	bool ok = false;
 	if (!reject) {
+		SRT_REGION(EXTEND_TRI_EXACT);
 		float f = 1.0f / a;
 		float u = f * sh;
 		ok = !(u < 0.0f || u > 1.0f);
@@ -660,9 +661,9 @@ __device__ __forceinline__ bool moller_trumbore(float v0x, float v0y, float v0z,
 template <bool COUNT_TRIS>
 __device__ __forceinline__ void test_triangle(float v0x, float v0y, float v0z, float e1x, float e1y, float e1z, float e2x, float e2y,
                                               float e2z, f3 org, f3 dir, int idx, uint32_t j, uint32_t count, float &tmin, int &best,
-                                              uint32_t &best_tri, uint32_t &n_tri_u) {
+                                              uint32_t &best_tri, uint32_t &n_tri_u SRT_RC_PARAM) {
 	float t = 0.0f;
-	if (moller_trumbore<COUNT_TRIS>(v0x, v0y, v0z, e1x, e1y, e1z, e2x, e2y, e2z, org, dir, j < count, t, n_tri_u) && t < tmin) {
+	if (moller_trumbore<COUNT_TRIS>(v0x, v0y, v0z, e1x, e1y, e1z, e2x, e2y, e2z, org, dir, j < count, t, n_tri_u SRT_RC_ARG) && t < tmin) {
 		tmin = t;
 		best = idx;
 		best_tri = j;
@@ -678,11 +679,11 @@ __device__ __forceinline__ void test_triangle(float v0x, float v0y, float v0z, f
 
 template <bool COUNT_TRIS>
 __device__ __forceinline__ void test_pair(const Tri2 &t, f3 org, f3 dir, int idx, uint32_t j, uint32_t count, float &tmin, int &best,
-                                          uint32_t &best_tri, uint32_t &n_tri_u) {
+                                          uint32_t &best_tri, uint32_t &n_tri_u SRT_RC_PARAM) {
 	test_triangle<COUNT_TRIS>(t.v[0], t.v[1], t.v[2], t.v[3], t.v[4], t.v[5], t.v[6], t.v[7], t.v[8], org, dir, idx, j, count, tmin, best, best_tri,
-	                          n_tri_u);
+	                          n_tri_u SRT_RC_ARG);
 	test_triangle<COUNT_TRIS>(t.v[9], t.v[10], t.v[11], t.v[12], t.v[13], t.v[14], t.v[15], t.v[16], t.v[17], org, dir, idx, j + 1u, count, tmin,
-	                          best, best_tri, n_tri_u);
+	                          best, best_tri, n_tri_u SRT_RC_ARG);
 }
 
 template <bool COUNT_TRIS>
@@ -694,9 +695,9 @@ __device__ __forceinline__ void test_triangles(const float *__restrict__ wtris, 
 	for (uint32_t b = 0; b < npair; b += 2) {
 		SRT_REGION(EXTEND_TRI_LOOP);
 		const Tri2 c = ld_tri2(blk + 18u * (b + 1u)); // in flight while `a` is tested
-		test_pair<COUNT_TRIS>(a, org, dir, idx, 2u * b, count, tmin, best, best_tri, n_tri_u);
+		test_pair<COUNT_TRIS>(a, org, dir, idx, 2u * b, count, tmin, best, best_tri, n_tri_u SRT_RC_ARG);
 		a = ld_tri2(blk + 18u * (b + 2u)); // in flight while `c` is tested (one pair of slack is allocated past the end)
-		test_pair<COUNT_TRIS>(c, org, dir, idx, 2u * b + 2u, count, tmin, best, best_tri, n_tri_u);
+		test_pair<COUNT_TRIS>(c, org, dir, idx, 2u * b + 2u, count, tmin, best, best_tri, n_tri_u SRT_RC_ARG);
 	}
 }
 
@@ -765,7 +766,7 @@ __device__ __forceinline__ void walk_bvh(const float4 *__restrict__ blocks, BvhS
 			if (COUNT_TRIS) n_tri += cnt;
 			auto tri = [&](float v0x, float v0y, float v0z, float e1x, float e1y, float e1z, float e2x, float e2y, float e2z, float jf, uint32_t k) {
 				float t = 0.0f;
-				if (moller_trumbore<COUNT_TRIS>(v0x, v0y, v0z, e1x, e1y, e1z, e2x, e2y, e2z, org, dir, true, t, n_tri_u)) {
+				if (moller_trumbore<COUNT_TRIS>(v0x, v0y, v0z, e1x, e1y, e1z, e2x, e2y, e2z, org, dir, true, t, n_tri_u SRT_RC_ARG)) {
 					const uint32_t j = f2u(jf);
 					if (t < tmin || (t == tmin && best == idx && j < best_j)) {
 						tmin = t;

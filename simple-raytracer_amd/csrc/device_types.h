@@ -26,7 +26,7 @@ struct ShapeRun { /* host side only: a block while it is being packed */
 	uint32_t data_off;
 };
 struct BlockGroup {
-	uint32_t code;     /* byte k = block k of the group: (shape type + 1) | shapes in the block << 2 | big model << 5; 0 = no block */
+	uint32_t code;     /* byte k = block k of the group: (shape type + 1) | shapes in the block << 2 | big model << 5 | its scan stack << 6; 0 = no block */
 	uint32_t first[3]; /* index of each block's first shape */
 };
 static_assert(sizeof(BlockGroup) == 16, "BlockGroup 16 B");
@@ -110,7 +110,9 @@ struct TraceParams {
 	unsigned long long total_items;  /* owned pixels * batch_samples */
 	uint32_t batch_samples;          /* samples per pixel in this batch */
 	uint32_t first_sample;           /* sample index of the batch's first sample */
-	uint32_t job_items;              /* items a wave reserves per atomic (multiple of the LDS sub-job size) */
+	uint32_t job_items;              /* items of a chunk, the unit the work cursor hands out (multiple of the LDS sub-job size) */
+	uint32_t n_chunks;               /* ceil(total_items / job_items); the work cursor counts chunks */
+	uint32_t _pad5;
 	uint32_t stage_off;              /* float4 offset of the staging slots inside dynamic LDS */
 	int32_t sky_w, sky_h;
 	/* wave-uniform values precomputed on the host so they arrive in SGPRs instead of being
@@ -122,7 +124,7 @@ struct TraceParams {
 	int32_t rank, world, rows_per_block, owned_rows;
 	int32_t use_bvh;          /* model records carry a BVH root instead of a first world triangle */
 	const float *bvh_blocks;  /* all models' 128-byte blocks (wide hierarchy above) */
-	float *scan_queue;        /* array scan: 19 x 64 floats per persistent wave (rays that wait for a big model's triangle scan) */
+	float *scan_queue;        /* array scan: SRT_SCAN_QUEUE_FLOATS per persistent wave (rays that wait for a big model's triangle scan, parked rays) */
 	/* camera-ray set-up without per-lane integer or IEEE divisions (kernels.hip CAMERA; srt_abi.hip fills them per launch) */
 	float inv_f_width, inv_f_height;  /* 1.0f / f_width, 1.0f / f_height, correctly rounded on the host (srt_div_by_rcp in kernels.hip) */
 	uint32_t width_magic, width_shift; /* n / width = (mulhi(n, magic) + n) >> shift for n < 2^31 (srt_magic_u31) */
@@ -181,10 +183,11 @@ int srt_trace_resident_waves_per_cu(const TraceParams &p, bool count_triangles);
 int srt_scan_suspend_min(void); /* array scan: models of at least this many triangles sit alone in their block and are flagged big */
 int srt_sub_job_items(int has_models, int use_bvh); /* items per LDS-staged sub-job; chunks per atomic are multiples of it */
 int srt_scan_queue_in_hbm(void); /* 1: TraceParams.scan_queue must point at SRT_SCAN_QUEUE_FLOATS floats per wave of the launch */
-#ifndef SRT_SQ_CAP
-#define SRT_SQ_CAP 64
-#endif
-#define SRT_SCAN_QUEUE_FLOATS (20 * SRT_SQ_CAP)
+/* per persistent wave: two scan stacks of SRT_SQ_CAP records x 20 fields, one park stack of SRT_PK_CAP records x 15 fields.
+ * A scan stack is taken back when it holds 64 rays and one EXTEND phase pushes at most 64: 190 is the most one can hold. */
+#define SRT_SQ_CAP 192
+#define SRT_PK_CAP 256
+#define SRT_SCAN_QUEUE_FLOATS (2 * 20 * SRT_SQ_CAP + 15 * SRT_PK_CAP)
 int srt_bvh_suspends(void);
 void srt_launch_prepass(const PrepassParams &p, uint64_t total_wtris, void *stream);
 void srt_launch_resolve(const ResolveParams &p, void *stream);

@@ -48,7 +48,7 @@
 	X(EXTEND_PLANES_0) X(EXTEND_PLANES_1) X(EXTEND_PLANES_2) X(EXTEND_MODEL_0) X(EXTEND_MODEL_1) X(EXTEND_MODEL_2)                   \
 	X(EXTEND_TRI_LOOP) X(EXTEND_TRI_EXACT) X(EXTEND_BVH_STEP) X(EXTEND_FINISH) X(SKY_PUSH) X(SKY_RESOLVE) X(SHADE_HEAD) X(SHADE_POP) X(SHADE_WINNER)   \
 	X(SHADE_MESH_NORMAL) X(SHADE_MATERIAL) X(SHADE_BOUNCE) X(SHADE_OPAQUE) X(SHADE_GLASS) X(SHADE_REFRACT) X(SHADE_TAIL) X(PARK)     \
-	X(HANDIN) X(HANDIN_ORPHAN) X(REFILL_HEAD) X(REFILL_SCANQ) X(REFILL_LOOP) X(REFILL_OPEN) X(REFILL_FLUSH) X(REFILL_CURSOR)         \
+	X(HANDIN) X(HANDIN_ORPHAN) X(REFILL_HEAD) X(REFILL_SCANQ) X(REFILL_UNPARK) X(REFILL_LOOP) X(REFILL_OPEN) X(REFILL_FLUSH) X(REFILL_CURSOR)         \
 	X(REFILL_TAKE) X(CAMERA) X(LOOP_TAIL) X(EPILOGUE)
 enum SrtRegion {
 #define SRT_REGION_ENUM(n) R_##n,
@@ -921,13 +921,14 @@ __device__ __forceinline__ f3 sky_box(const TraceParams &p_live, f3 dir) {
 #define SRT_HQ_CAP 40
 #endif
 // Array-scan kernels: a model of at least this many triangles ("big", srt_abi.hip packs it alone in its block) is not
-// scanned by the few lanes whose rays happen to enter its box in one EXTEND phase; those rays wait in the scan
-// queue until a wave-full of them has gathered (unless at least SRT_SCAN_NOW_MIN lanes want the scan anyway).
+// scanned by the few lanes whose rays happen to enter its box in one EXTEND phase; those rays wait in one of the
+// wave's two scan stacks (the host deals the big models out to them) until SRT_SCAN_FULL of them have gathered.
 #ifndef SRT_SCAN_SUSPEND_MIN
 #define SRT_SCAN_SUSPEND_MIN 128
 #endif
-#ifndef SRT_SCAN_NOW_MIN
-#define SRT_SCAN_NOW_MIN 48
+// a scan stack is taken back -- by ALL lanes of the wave; the rays they hold meanwhile are parked -- once it holds this many rays
+#ifndef SRT_SCAN_FULL
+#define SRT_SCAN_FULL 64
 #endif
 #ifndef SRT_HQ_CAP_BVH
 #define SRT_HQ_CAP_BVH SRT_HQ_CAP
@@ -1041,14 +1042,8 @@ __device__ __forceinline__ void resolve_ring(const TraceParams &p, const float *
 #ifndef SRT_BVH_SUSPEND
 #define SRT_BVH_SUSPEND 0 // BVH kernels gather the rays that enter a big model's box before they walk, as the array scan does
 #endif
-#ifndef SRT_SQ_CAP
-#define SRT_SQ_CAP 64 // records of the scan queue when it lives in HBM (device_types.h SRT_SCAN_QUEUE_FLOATS follows)
-#endif
-#ifndef SRT_SQ_GLOBAL
-#define SRT_SQ_GLOBAL 1 // array-scan kernels: the scan queue in HBM (0: in LDS, 13 instead of 20 waves per CU)
-#endif
 #ifndef SRT_TRACE_WAVES_PER_SIMD_MODELS
-#define SRT_TRACE_WAVES_PER_SIMD_MODELS (SRT_SQ_GLOBAL ? 5 : 4)
+#define SRT_TRACE_WAVES_PER_SIMD_MODELS 5
 #endif
 #ifndef SRT_TRACE_WAVES_PER_SIMD_BVH
 #define SRT_TRACE_WAVES_PER_SIMD_BVH 4
@@ -1107,9 +1102,10 @@ __global__ __launch_bounds__(64, USE_BVH ? SRT_TRACE_WAVES_PER_SIMD_BVH : HAS_MO
 	// radiances up per pixel in sample order.
 	const uint32_t total_items = (uint32_t)p.total_items;
 	const uint32_t nbs = p.batch_samples;
-	const unsigned long long own_chunks_end = (unsigned long long)gridDim.x * p.job_items;
+	// (the work cursor counts chunks)
+	const uint32_t n_chunks = p.n_chunks;
 	uint32_t chunk_cur = 0, chunk_end = 0; // wave-uniform
-	if ((unsigned long long)blockIdx.x * p.job_items < (unsigned long long)total_items) {
+	if (blockIdx.x < n_chunks) {
 		chunk_cur = blockIdx.x * p.job_items;
 		chunk_end = (total_items - chunk_cur < p.job_items) ? total_items : chunk_cur + p.job_items;
 	}
@@ -1122,24 +1118,26 @@ __global__ __launch_bounds__(64, USE_BVH ? SRT_TRACE_WAVES_PER_SIMD_BVH : HAS_MO
 	float *__restrict__ hq = ring + 10u * (uint32_t)SRT_RING_CAP;                                 // [16..18][HQ] paths that hit, awaiting their bounce (FIFO)
 	constexpr uint32_t HQ = USE_BVH ? SRT_HQ_CAP_BVH : SRT_HQ_CAP;
 #ifdef SRT_REGION_COUNT
-	uint32_t *region_ctr = reinterpret_cast<uint32_t *>(hq + (HAS_MODELS ? (USE_BVH ? 18u : 17u) : 16u) * HQ + (HAS_MODELS && !USE_BVH && !SRT_SQ_GLOBAL ? 19u * 64u : 0u));
+	uint32_t *region_ctr = reinterpret_cast<uint32_t *>(hq + (HAS_MODELS ? (USE_BVH ? 18u : 17u) : 16u) * HQ);
 	for (int i = lane; i < 2 * SRT_REGION_MAX; i += 64) region_ctr[i] = 0u;
 	__syncthreads();
 #endif
-	// array-scan kernels: rays waiting for the triangle scan of a big model (stack of 64 records x 19 fields)
+	// Array-scan kernels: rays waiting for the triangle scan of a big model. A scan costs the wave its triangle count whether
+	// one lane takes part or all 64, so a scan is started for a FULL wave of rays only. Every persistent wave owns, in HBM
+	// (device_types.h SRT_SCAN_QUEUE_FLOATS):
+	//   two scan stacks of SQ records x 20 fields -- the ray with everything closest_intersection has found so far and the
+	//   block it continues at; big model number k of the scene uses stack k & 1, so that the rays one stack gives back all
+	//   scan the same model (a scene of one or two big models; with more, a stack mixes models and its scans are less full);
+	//   one park stack of PK records x 15 fields -- rays that were about to set out when the wave took a scan stack back.
+	// In LDS the stacks would cost the kernel most of its waves; a record is written and read once per triangle scan of at
+	// least 128 triangles -- microseconds of memory latency against tens of microseconds of scanning. Stores are plain
+	// (write-through), loads bypass the vector L1 (a slot is reused, and the L1 keeps no track of this CU's own stores) and
+	// wait for the wave's stores first (REFILL below).
 	constexpr bool SUSPEND = HAS_MODELS && (!USE_BVH || SRT_BVH_SUSPEND);
-	constexpr uint32_t SQ = SRT_SQ_GLOBAL ? (uint32_t)SRT_SQ_CAP : 64u;
-#if SRT_SQ_GLOBAL
-	// The scan queue lives in HBM, one 19 x 64 record block per persistent wave: in LDS it cost the array-scan kernels
-	// a third of their waves (11.7 KB per wave: 13 per CU; without it 6.8 KB and the register file's 20). A record is
-	// written and read once per triangle scan of at least 128 triangles -- microseconds of memory latency against tens of
-	// microseconds of scanning. Stores are plain (write-through), loads bypass the vector L1 (a slot is reused, and the L1
-	// keeps no track of this CU's own stores) and wait for the wave's stores first (pop below).
-	float *__restrict__ sq = SUSPEND ? const_cast<float *>((const float *)SRT_COLD(p).scan_queue) + (size_t)blockIdx.x * (20u * SQ) : nullptr;
-#else
-	float *__restrict__ sq = hq + (HAS_MODELS ? (USE_BVH ? 18u : 17u) : 16u) * HQ;
-#endif
-	uint32_t sq_count = 0; // wave-uniform
+	constexpr uint32_t SQ = (uint32_t)SRT_SQ_CAP, PK = (uint32_t)SRT_PK_CAP;
+	float *__restrict__ sq_base = SUSPEND ? const_cast<float *>((const float *)SRT_COLD(p).scan_queue) + (size_t)blockIdx.x * (size_t)SRT_SCAN_QUEUE_FLOATS : nullptr;
+	float *__restrict__ pk = sq_base + 2u * 20u * SQ;
+	uint32_t sq_count0 = 0, sq_count1 = 0, pk_count = 0; // wave-uniform
 	uint32_t ring_count = 0, hq_head = 0, hq_count = 0;                        // wave-uniform
 
 	f3 org = mk(0.f, 0.f, 0.f), dir = mk(0.f, 0.f, 0.f), mask = mk(1.f, 1.f, 1.f), color = mk(0.f, 0.f, 0.f);
@@ -1170,7 +1168,7 @@ __global__ __launch_bounds__(64, USE_BVH ? SRT_TRACE_WAVES_PER_SIMD_BVH : HAS_MO
 	for (;;) {
 		SRT_REGION(LOOP_HEAD);
 		bool hit = false, missed = false, fin = false;
-		bool suspended = false; // SUSPEND: the lane's ray went to the scan queue in this iteration
+		bool suspended0 = false, suspended1 = false; // SUSPEND: the lane's ray went to scan stack 0 / 1 in this iteration
 		if (SRT_DIAG_ON) w_iter++;
 		SRT_CLK(6);
 		// ================= EXTEND: closest_intersection (render.cl:293-378), winner deferred =================
@@ -1195,8 +1193,8 @@ __global__ __launch_bounds__(64, USE_BVH ? SRT_TRACE_WAVES_PER_SIMD_BVH : HAS_MO
 						pos = 0;
 					}
 					bool part = true;       // SUSPEND: false once the ray has gone to the scan queue
-					uint32_t sq_pushed = 0; // records pushed by this EXTEND phase so far. Uniform among the lanes in here only:
-					                        // sq_count itself, which the lanes outside this branch read too, is brought up to date after it
+					uint32_t sq_pushed0 = 0, sq_pushed1 = 0; // records pushed by this EXTEND phase so far. Uniform among the lanes in here only:
+					                                          // the counts, which the lanes outside this branch read too, are brought up to date after it
 					f3 inv = mk(0.f, 0.f, 0.f);
 					if (HAS_MODELS) inv = mk(1.0f / dir.x, 1.0f / dir.y, 1.0f / dir.z);
 
@@ -1233,15 +1231,20 @@ __global__ __launch_bounds__(64, USE_BVH ? SRT_TRACE_WAVES_PER_SIMD_BVH : HAS_MO
 							bool scan0 = enter0;
 							if (SUSPEND && ((code >> 5) & 1u)) {
 								// A big model. Few of a wave's rays enter its box at a time; scanning 10^5 triangles for them would
-								// leave the other lanes idle. Those rays wait in the scan queue -- with everything closest_intersection
-								// has found so far, so that they continue exactly where they left -- until a wave-full has gathered.
+								// leave the other lanes idle. Those rays wait in the model's scan stack -- with everything
+								// closest_intersection has found so far, so that they continue exactly where they left -- until a wave-full
+								// has gathered. The scan runs now when the wave holds rays that were taken back for THIS block (a ray that
+								// has scanned one big model and enters the next one's box waits again), or when the stack is full.
 								const unsigned long long want = ballot64(enter0);
 								const uint32_t n_want = (uint32_t)__popcll(want);
-								const bool now = queue_dry || n_want >= (uint32_t)SRT_SCAN_NOW_MIN || sq_count + sq_pushed + n_want > SQ || any64(enter0 && resumed);
+								const uint32_t sid = (code >> 6) & 1u; // (wave-uniform) the model's stack
+								const uint32_t held = sid ? sq_count1 + sq_pushed1 : sq_count0 + sq_pushed0;
+								const bool now = held + n_want > SQ || any64(enter0 && resumed && pos == bidx);
 								if (!now) {
 									if (enter0) {
 										SRT_REGION(EXTEND_SUSPEND);
-										const uint32_t e = sq_count + sq_pushed + __builtin_amdgcn_mbcnt_hi((uint32_t)(want >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)want, 0u));
+										float *__restrict__ sq = sq_base + sid * (20u * SQ);
+										const uint32_t e = held + __builtin_amdgcn_mbcnt_hi((uint32_t)(want >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)want, 0u));
 										sq[0 * SQ + e] = org.x, sq[1 * SQ + e] = org.y, sq[2 * SQ + e] = org.z;
 										sq[3 * SQ + e] = dir.x, sq[4 * SQ + e] = dir.y, sq[5 * SQ + e] = dir.z;
 										sq[6 * SQ + e] = mask.x, sq[7 * SQ + e] = mask.y, sq[8 * SQ + e] = mask.z;
@@ -1251,9 +1254,11 @@ __global__ __launch_bounds__(64, USE_BVH ? SRT_TRACE_WAVES_PER_SIMD_BVH : HAS_MO
 										sq[18 * SQ + e] = dm_u2f(bidx);
 										if (USE_BVH) sq[19 * SQ + e] = dm_u2f(best_j);
 										part = false;
-										suspended = true;
+										if (sid) suspended1 = true;
+										else suspended0 = true;
 									}
-									sq_pushed += n_want;
+									if (sid) sq_pushed1 += n_want;
+									else sq_pushed0 += n_want;
 									scan0 = false;
 								}
 							}
@@ -1355,7 +1360,10 @@ __global__ __launch_bounds__(64, USE_BVH ? SRT_TRACE_WAVES_PER_SIMD_BVH : HAS_MO
 			}
 		}
 
-		if (SUSPEND) sq_count += (uint32_t)__popcll(ballot64(suspended)); // wave-uniform again
+		if (SUSPEND) { // wave-uniform again
+			sq_count0 += (uint32_t)__popcll(ballot64(suspended0));
+			sq_count1 += (uint32_t)__popcll(ballot64(suspended1));
+		}
 		SRT_CLK(0);
 		// ---- escaped paths queue for the sky (wave-uniform control flow) ----
 		const unsigned long long mm = ballot64(missed);
@@ -1601,38 +1609,74 @@ __global__ __launch_bounds__(64, USE_BVH ? SRT_TRACE_WAVES_PER_SIMD_BVH : HAS_MO
 		unsigned long long freeb = ballot64(!active);
 		uint32_t n_free = (uint32_t)__popcll(freeb);
 		n_active = 64u - n_free;
-		if (SUSPEND && sq_count != 0u && n_free != 0u &&
-		    (queue_dry || (n_free >= (uint32_t)SRT_REFILL_MIN && sq_count >= (n_free < (uint32_t)SRT_SCAN_NOW_MIN ? n_free : (uint32_t)SRT_SCAN_NOW_MIN)))) {
-			SRT_REGION(REFILL_SCANQ);
-			// rays that wait for a big model's triangle scan come first: together they fill the wave for it
-			asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); // the records' stores have arrived (LDS, or HBM: acknowledged by the L2)
-			const uint32_t n_pop = n_free < sq_count ? n_free : sq_count;
-			const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(freeb >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)freeb, 0u));
-			if (!active && rank < n_pop) {
-				const uint32_t e = sq_count - 1u - rank;
-#if SRT_SQ_GLOBAL
-				auto rd = [&](uint32_t k) { return dm_u2f(__hip_atomic_load(reinterpret_cast<const uint32_t *>(sq) + k * SQ + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)); };
-#else
-				auto rd = [&](uint32_t k) { return sq[k * SQ + e]; };
-#endif
-				org = mk(rd(0), rd(1), rd(2));
-				dir = mk(rd(3), rd(4), rd(5));
-				mask = mk(rd(6), rd(7), rd(8));
-				color = mk(rd(9), rd(10), rd(11));
-				seed = dm_f2u(rd(12)), bounce = (int)dm_f2u(rd(13)), item = dm_f2u(rd(14));
-				tmin = rd(15), best = (int)dm_f2u(rd(16)), best_tri = dm_f2u(rd(17));
-				pos = dm_f2u(rd(18));
-				if (USE_BVH) best_j = dm_f2u(rd(19));
-				resumed = true;
-				active = true;
+		if (SUSPEND) {
+			// A scan stack that holds a wave-full is taken back by ALL 64 lanes: the scan then runs without an idle lane. Rays the
+			// lanes hold at this point -- bounced or new, about to set out -- are parked and come back into lanes that fall free.
+			// At the very end (no camera ray left, nothing else under way) the fuller stack is taken back as it is.
+			const bool full0 = sq_count0 >= (uint32_t)SRT_SCAN_FULL, full1 = sq_count1 >= (uint32_t)SRT_SCAN_FULL;
+			const bool rest = queue_dry && n_active == 0u && hq_count == 0u && pk_count == 0u && (sq_count0 | sq_count1) != 0u;
+			auto ld = [&](const float *a) { return dm_u2f(__hip_atomic_load(reinterpret_cast<const uint32_t *>(a), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)); };
+			if ((full0 || full1 || rest) && pk_count + n_active <= PK) {
+				SRT_REGION(REFILL_SCANQ);
+				if (n_active != 0u) {
+					const unsigned long long ab = ~freeb;
+					const uint32_t e = pk_count + __builtin_amdgcn_mbcnt_hi((uint32_t)(ab >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)ab, 0u));
+					if (active) {
+						pk[0 * PK + e] = org.x, pk[1 * PK + e] = org.y, pk[2 * PK + e] = org.z;
+						pk[3 * PK + e] = dir.x, pk[4 * PK + e] = dir.y, pk[5 * PK + e] = dir.z;
+						pk[6 * PK + e] = mask.x, pk[7 * PK + e] = mask.y, pk[8 * PK + e] = mask.z;
+						pk[9 * PK + e] = color.x, pk[10 * PK + e] = color.y, pk[11 * PK + e] = color.z;
+						pk[12 * PK + e] = dm_u2f(seed), pk[13 * PK + e] = dm_u2f((uint32_t)bounce), pk[14 * PK + e] = dm_u2f(item);
+					}
+					pk_count += n_active;
+				}
+				const uint32_t sid = full0 ? 0u : full1 ? 1u : (sq_count1 > sq_count0 ? 1u : 0u);
+				const uint32_t held = sid ? sq_count1 : sq_count0;
+				const uint32_t n_pop = held < 64u ? held : 64u;
+				const float *__restrict__ sq = sq_base + sid * (20u * SQ);
+				asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the records' stores have arrived (acknowledged by the L2)
+				active = (uint32_t)lane < n_pop;
+				if (active) {
+					const uint32_t e = held - 1u - (uint32_t)lane;
+					org = mk(ld(sq + 0 * SQ + e), ld(sq + 1 * SQ + e), ld(sq + 2 * SQ + e));
+					dir = mk(ld(sq + 3 * SQ + e), ld(sq + 4 * SQ + e), ld(sq + 5 * SQ + e));
+					mask = mk(ld(sq + 6 * SQ + e), ld(sq + 7 * SQ + e), ld(sq + 8 * SQ + e));
+					color = mk(ld(sq + 9 * SQ + e), ld(sq + 10 * SQ + e), ld(sq + 11 * SQ + e));
+					seed = dm_f2u(ld(sq + 12 * SQ + e)), bounce = (int)dm_f2u(ld(sq + 13 * SQ + e)), item = dm_f2u(ld(sq + 14 * SQ + e));
+					tmin = ld(sq + 15 * SQ + e), best = (int)dm_f2u(ld(sq + 16 * SQ + e)), best_tri = dm_f2u(ld(sq + 17 * SQ + e));
+					pos = dm_f2u(ld(sq + 18 * SQ + e));
+					if (USE_BVH) best_j = dm_f2u(ld(sq + 19 * SQ + e));
+					resumed = true;
+				}
+				asm volatile("" ::: "memory");
+				if (sid) sq_count1 -= n_pop;
+				else sq_count0 -= n_pop;
+				n_active = n_pop;
+				freeb = ballot64(!active);
+				n_free = 64u - n_pop;
+			} else if (pk_count != 0u && n_free != 0u) {
+				SRT_REGION(REFILL_UNPARK);
+				asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+				const uint32_t n_pop = n_free < pk_count ? n_free : pk_count;
+				const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(freeb >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)freeb, 0u));
+				if (!active && rank < n_pop) {
+					const uint32_t e = pk_count - 1u - rank;
+					org = mk(ld(pk + 0 * PK + e), ld(pk + 1 * PK + e), ld(pk + 2 * PK + e));
+					dir = mk(ld(pk + 3 * PK + e), ld(pk + 4 * PK + e), ld(pk + 5 * PK + e));
+					mask = mk(ld(pk + 6 * PK + e), ld(pk + 7 * PK + e), ld(pk + 8 * PK + e));
+					color = mk(ld(pk + 9 * PK + e), ld(pk + 10 * PK + e), ld(pk + 11 * PK + e));
+					seed = dm_f2u(ld(pk + 12 * PK + e)), bounce = (int)dm_f2u(ld(pk + 13 * PK + e)), item = dm_f2u(ld(pk + 14 * PK + e));
+					resumed = false;
+					active = true;
+				}
+				asm volatile("" ::: "memory");
+				pk_count -= n_pop;
+				n_active += n_pop;
+				freeb = ballot64(!active);
+				n_free -= n_pop;
 			}
-			asm volatile("" ::: "memory");
-			sq_count -= n_pop;
-			n_active += n_pop;
-			freeb = ballot64(!active);
-			n_free = (uint32_t)__popcll(freeb);
 		}
-		if (!queue_dry && n_free >= (uint32_t)SRT_REFILL_MIN) {
+		if (!queue_dry && n_free >= (uint32_t)SRT_REFILL_MIN && (!SUSPEND || pk_count == 0u)) {
 			const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(freeb >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)freeb, 0u));
 			uint32_t given = 0; // free lanes served so far (wave-uniform)
 			bool got = false;
@@ -1658,21 +1702,22 @@ __global__ __launch_bounds__(64, USE_BVH ? SRT_TRACE_WAVES_PER_SIMD_BVH : HAS_MO
 					}
 					if (chunk_cur == chunk_end) {
 						SRT_REGION(REFILL_CURSOR);
-						unsigned long long start = total_items;
-						if (own_chunks_end < (unsigned long long)total_items) { // else every chunk is some wave's first: nothing to ask the cursor for
-							if (lane == 0) start = atomicAdd((unsigned long long *)SRT_COLD(p).queue, (unsigned long long)SRT_COLD(p).job_items);
+						unsigned long long k = n_chunks; // ordinal of the next chunk
+						if (gridDim.x < n_chunks) { // else every chunk is some wave's first: nothing to ask the cursor for
+							unsigned long long got_k = 0;
+							if (lane == 0) got_k = atomicAdd((unsigned long long *)SRT_COLD(p).queue, 1ull);
 							// lane 0's value as a scalar (wave-uniform control flow: lane 0 is active), so that everything derived from
 							// it -- chunk bounds, sub-job bases -- stays in SGPRs
-							const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)start);
-							const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(start >> 32));
-							start = (((unsigned long long)hi << 32) | lo) + own_chunks_end;
+							const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)got_k);
+							const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(got_k >> 32));
+							k = (((unsigned long long)hi << 32) | lo) + gridDim.x;
 						}
-						if (start >= (unsigned long long)total_items) {
+						if (k >= (unsigned long long)n_chunks) {
 							queue_dry = true;
 							break;
 						}
-						chunk_cur = (uint32_t)start;
 						const uint32_t job_items = SRT_COLD(p).job_items;
+						chunk_cur = (uint32_t)k * job_items;
 						chunk_end = (total_items - chunk_cur < job_items) ? total_items : chunk_cur + job_items;
 					}
 					const uint32_t left = chunk_end - chunk_cur;
@@ -1754,7 +1799,7 @@ __global__ __launch_bounds__(64, USE_BVH ? SRT_TRACE_WAVES_PER_SIMD_BVH : HAS_MO
 
 		SRT_CLK(5);
 		SRT_REGION(LOOP_TAIL);
-		if (n_active == 0u && hq_count == 0u && sq_count == 0u) {
+		if (n_active == 0u && hq_count == 0u && (sq_count0 | sq_count1 | pk_count) == 0u) {
 			if (queue_dry) break;
 			// Bounded: a wave that spins here without ever getting work leaves with the watchdog counter set instead of hanging.
 			if (++idle_spins > (1u << 20)) {
@@ -2048,14 +2093,14 @@ int srt_trace_waves_per_simd(int has_models, int use_bvh) {
 	return !has_models ? SRT_TRACE_WAVES_PER_SIMD : use_bvh ? SRT_TRACE_WAVES_PER_SIMD_BVH : SRT_TRACE_WAVES_PER_SIMD_MODELS;
 }
 int srt_scan_suspend_min(void) { return SRT_SCAN_SUSPEND_MIN; }
-int srt_scan_queue_in_hbm(void) { return SRT_SQ_GLOBAL; }
+int srt_scan_queue_in_hbm(void) { return 1; }
 int srt_bvh_suspends(void) { return SRT_BVH_SUSPEND; }
 int srt_sub_job_items(int has_models, int use_bvh) { return !has_models ? SRT_SUB_PLAIN : use_bvh ? SRT_SUB_BVH : SRT_SUB_MODELS; }
 
 int srt_trace_lds_floats(int has_models, int use_bvh) {
 	// two staging buffers of packed 12-byte items, the sky ring (10 fields), the hit queue (16..18 fields)
 	const int sub = srt_sub_job_items(has_models, use_bvh);
-	int n = 2 * sub * 3 + 10 * SRT_RING_CAP + (has_models ? (use_bvh ? 18 * SRT_HQ_CAP_BVH : 17 * SRT_HQ_CAP) : 16 * SRT_HQ_CAP) + (has_models && !use_bvh && !SRT_SQ_GLOBAL ? 19 * 64 : 0);
+	int n = 2 * sub * 3 + 10 * SRT_RING_CAP + (has_models ? (use_bvh ? 18 * SRT_HQ_CAP_BVH : 17 * SRT_HQ_CAP) : 16 * SRT_HQ_CAP);
 #ifdef SRT_REGION_COUNT
 	n += 2 * SRT_REGION_MAX; // (waves, lanes) per region
 #endif

@@ -758,10 +758,12 @@ static int update_scene_impl(srt_tracer *t, const srt_shape *shapes, size_t n_sh
 	pad_run();
 	// group headers: three blocks each (device_types.h BlockGroup); the data of a last, partial group is zero-filled
 	std::vector<BlockGroup> groups((runs.size() + 2) / 3);
+	uint32_t n_big = 0; // big model number k waits in scan stack k & 1 (kernels.hip)
 	for (size_t b = 0; b < runs.size(); b++) {
 		BlockGroup &g = groups[b / 3];
 		if (b % 3 == 0) memset(&g, 0, sizeof g);
-		g.code |= (((uint32_t)runs[b].type + 1u) | (runs[b].count << 2) | ((runs[b].data_off >> 31) << 5)) << (8 * (b % 3));
+		const uint32_t big = runs[b].data_off >> 31;
+		g.code |= (((uint32_t)runs[b].type + 1u) | (runs[b].count << 2) | (big << 5) | ((big ? (n_big++ & 1u) : 0u) << 6)) << (8 * (b % 3));
 		g.first[b % 3] = runs[b].first_shape;
 	}
 	data.resize(groups.size() * 48 + 16, 0.0f);
@@ -969,7 +971,10 @@ int srt_trace(srt_tracer *t, const srt_render_data *options) {
 		// batches of 8 / 16 / 32 samples one after the other 15.0 / - / 7.9 s, overlapped 8.5 / 6.8 / 6.4 s.
 		if (t->scan_tris > 4096) {
 			const double per_sample = (double)pixels * (double)t->scan_tris;
-			const double cap = SRT_SCAN_PAIRS_PER_LAUNCH / per_sample;
+			double pairs = SRT_SCAN_PAIRS_PER_LAUNCH;
+			if (const char *env = getenv("SRT_SCAN_PAIRS")) // experiments only
+				if (atof(env) > 0.0) pairs = atof(env);
+			const double cap = pairs / per_sample;
 			const uint32_t cap_u = cap < 1.0 ? 1u : (cap > 1e9 ? 0xffffffffu : (uint32_t)cap);
 			if (cap_u < batch) batch = cap_u;
 		}
@@ -1002,7 +1007,7 @@ int srt_trace(srt_tracer *t, const srt_render_data *options) {
 	if (slots > SRT_WAVE_CTR_SLOTS) slots = SRT_WAVE_CTR_SLOTS; // one counter line per persistent wave
 
 	if (t->num_models > 0 && (!t->bvh_active || srt_bvh_suspends()) && srt_scan_queue_in_hbm()) // one block per persistent wave, two sets (overlapping batches)
-		SRT_HIP(t, t->scan_queue.reserve((size_t)2 * SRT_WAVE_CTR_SLOTS * SRT_SCAN_QUEUE_FLOATS));
+		SRT_HIP(t, t->scan_queue.reserve((size_t)2 * slots * SRT_SCAN_QUEUE_FLOATS)); // (46 KB per wave: 2 x 236 MB on 256 CUs)
 
 	ReduceParams rp;
 	rp.radiance = t->radiance.ptr;
@@ -1055,7 +1060,7 @@ int srt_trace(srt_tracer *t, const srt_render_data *options) {
 		rp.radiance = p.radiance;
 		p.queue = t->counters.ptr + (par ? SRT_CTR_QUEUE2 : SRT_CTR_QUEUE);
 		p.wave_counters = t->wave_counters.ptr + (size_t)par * SRT_WAVE_CTR_SLOTS * SRT_WAVE_CTR_STRIDE;
-		p.scan_queue = t->scan_queue.ptr ? t->scan_queue.ptr + (size_t)par * SRT_WAVE_CTR_SLOTS * SRT_SCAN_QUEUE_FLOATS : nullptr;
+		p.scan_queue = t->scan_queue.ptr ? t->scan_queue.ptr + (size_t)par * slots * SRT_SCAN_QUEUE_FLOATS : nullptr;
 		if (overlap && b >= 2) SRT_HIP(t, hipStreamWaitEvent(ts, t->ev_batch_reduced[par], 0)); // batch b - 2 has been summed up
 		const uint32_t s0 = b * batch;
 		const uint32_t nbs = (uint32_t)ns - s0 < batch ? (uint32_t)ns - s0 : batch;
@@ -1092,6 +1097,7 @@ int srt_trace(srt_tracer *t, const srt_render_data *options) {
 		const unsigned long long job_cap = cap_subs * sub;
 		if (job > job_cap) job = job_cap;
 		p.job_items = (uint32_t)job;
+		p.n_chunks = (uint32_t)((p.total_items + job - 1ull) / job);
 		const unsigned long long waves_needed = (p.total_items + 63ull) / 64ull;
 		const int num_waves = (int)(waves_needed < slots_b ? waves_needed : slots_b);
 		SRT_HIP(t, hipMemsetAsync(p.queue, 0, sizeof(unsigned long long), ts));

@@ -33,6 +33,6 @@ for spec in sys.argv[1].split(","):
         ms.append(t.last_trace_kernel_ms())
     d = t.debug_counters()
     out[spec] = {"kernel_ms_min": round(min(ms[1:]), 3), "kernel_ms_all": [round(x, 2) for x in ms[1:]], "checksum": float(np.nansum(t.read_canvas().astype(np.float64))),
-                 "scans": d.get("scans"), "scan_lanes": d.get("scan_lanes")}
+                 "scans": d.get("scans"), "scan_lanes": d.get("scan_lanes"), "pool": [d.get("pool_taken"), d.get("pool_given"), d.get("pool_taken_sq"), d.get("pool_last_taken")], "iterations": d.get("iterations")}
     t.close()
 print(json.dumps(out))

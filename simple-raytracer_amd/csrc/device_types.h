@@ -77,7 +77,7 @@ typedef srt_bvh_node BvhNode; /* include/srt_types.h */
  * summed on the host when asked for: thousands of waves ending together on three shared atomics
  * cost a small dispatch 100 us (profiles/README.md). Launches of a handle are stream-ordered and a
  * launch has one wave per index, so a plain read-modify-write is enough. */
-#define SRT_REGION_MAX 48 /* kernels.hip SRT_REGION_LIST: regions of the trace kernel a -DSRT_REGION_COUNT build counts (waves, lanes) for */
+#define SRT_REGION_MAX 56 /* kernels.hip SRT_REGION_LIST: regions of the trace kernel a -DSRT_REGION_COUNT build counts (waves, lanes) for */
 #ifdef SRT_REGION_COUNT
 #define SRT_WAVE_CTR_STRIDE (16 + 2 * SRT_REGION_MAX)
 #else
@@ -110,9 +110,7 @@ struct TraceParams {
 	unsigned long long total_items;  /* owned pixels * batch_samples */
 	uint32_t batch_samples;          /* samples per pixel in this batch */
 	uint32_t first_sample;           /* sample index of the batch's first sample */
-	uint32_t job_items;              /* items of a chunk, the unit the work cursor hands out (multiple of the LDS sub-job size) */
-	uint32_t n_chunks;               /* ceil(total_items / job_items); the work cursor counts chunks */
-	uint32_t _pad5;
+	uint32_t job_items;              /* items a wave reserves per atomic (multiple of the LDS sub-job size) */
 	uint32_t stage_off;              /* float4 offset of the staging slots inside dynamic LDS */
 	int32_t sky_w, sky_h;
 	/* wave-uniform values precomputed on the host so they arrive in SGPRs instead of being
@@ -124,13 +122,14 @@ struct TraceParams {
 	int32_t rank, world, rows_per_block, owned_rows;
 	int32_t use_bvh;          /* model records carry a BVH root instead of a first world triangle */
 	const float *bvh_blocks;  /* all models' 128-byte blocks (wide hierarchy above) */
-	float *scan_queue;        /* array scan: SRT_SCAN_QUEUE_FLOATS per persistent wave (rays that wait for a big model's triangle scan, parked rays) */
+	float *scan_queue;        /* array scan: SRT_POOL_CTL_WORDS words of pool control (zeroed before the launch), SRT_POOL_REC_FLOATS of pool records, then
+	                             SRT_SCAN_QUEUE_FLOATS per persistent wave (rays that wait for a big model's triangle scan, parked rays) */
 	/* camera-ray set-up without per-lane integer or IEEE divisions (kernels.hip CAMERA; srt_abi.hip fills them per launch) */
 	float inv_f_width, inv_f_height;  /* 1.0f / f_width, 1.0f / f_height, correctly rounded on the host (srt_div_by_rcp in kernels.hip) */
 	uint32_t width_magic, width_shift; /* n / width = (mulhi(n, magic) + n) >> shift for n < 2^31 (srt_magic_u31) */
 	uint32_t rpb_magic, rpb_shift;     /* the same for rows_per_block */
 	uint32_t nbs_magic16;              /* n / batch_samples = (n * magic16) >> 16 for n < 256, when batch_samples < 128 (else unused) */
-	uint32_t _pad4;
+	uint32_t pool_on;                  /* array scan, end of a launch: the waves' leftover rays are pooled (kernels.hip; 0 = every wave scans its own remainder) */
 	int32_t unit_materials;            /* the device materials hold bernoulli() thresholds in place of metallic / specular / transmittance */
 	int32_t all_materials_ok;          /* no shape with a negative material index: the closest shape is a hit without looking its material up (render.cl:404) */
 };
@@ -188,6 +187,10 @@ int srt_scan_queue_in_hbm(void); /* 1: TraceParams.scan_queue must point at SRT_
 #define SRT_SQ_CAP 192
 #define SRT_PK_CAP 256
 #define SRT_SCAN_QUEUE_FLOATS (2 * 20 * SRT_SQ_CAP + 15 * SRT_PK_CAP)
+#define SRT_POOL_BLOCKS 8192 /* per stack: 524,288 rays (a launch's ~5,000 waves hand in fewer than 64 each, and again after each bounce) */
+#define SRT_POOL_CTL_WORDS (16 + 2 * SRT_POOL_BLOCKS)
+#define SRT_POOL_REC_FLOATS ((size_t)2 * SRT_POOL_BLOCKS * 20 * 64)
+#define SRT_SCAN_SET_FLOATS(waves) ((size_t)SRT_POOL_CTL_WORDS + SRT_POOL_REC_FLOATS + (size_t)(waves) * SRT_SCAN_QUEUE_FLOATS) /* one set; a multiple of 4 */
 int srt_bvh_suspends(void);
 void srt_launch_prepass(const PrepassParams &p, uint64_t total_wtris, void *stream);
 void srt_launch_resolve(const ResolveParams &p, void *stream);

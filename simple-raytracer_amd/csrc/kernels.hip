@@ -48,7 +48,7 @@
 	X(EXTEND_PLANES_0) X(EXTEND_PLANES_1) X(EXTEND_PLANES_2) X(EXTEND_MODEL_0) X(EXTEND_MODEL_1) X(EXTEND_MODEL_2)                   \
 	X(EXTEND_TRI_LOOP) X(EXTEND_TRI_EXACT) X(EXTEND_BVH_STEP) X(EXTEND_FINISH) X(SKY_PUSH) X(SKY_RESOLVE) X(SHADE_HEAD) X(SHADE_POP) X(SHADE_WINNER)   \
 	X(SHADE_MESH_NORMAL) X(SHADE_MATERIAL) X(SHADE_BOUNCE) X(SHADE_OPAQUE) X(SHADE_GLASS) X(SHADE_REFRACT) X(SHADE_TAIL) X(PARK)     \
-	X(HANDIN) X(HANDIN_ORPHAN) X(REFILL_HEAD) X(REFILL_SCANQ) X(REFILL_UNPARK) X(REFILL_LOOP) X(REFILL_OPEN) X(REFILL_FLUSH) X(REFILL_CURSOR)         \
+	X(HANDIN) X(HANDIN_ORPHAN) X(REFILL_HEAD) X(REFILL_SCANQ) X(REFILL_POOL) X(REFILL_UNPARK) X(REFILL_LOOP) X(REFILL_OPEN) X(REFILL_FLUSH) X(REFILL_CURSOR)         \
 	X(REFILL_TAKE) X(CAMERA) X(LOOP_TAIL) X(EPILOGUE)
 enum SrtRegion {
 #define SRT_REGION_ENUM(n) R_##n,
@@ -964,13 +964,31 @@ namespace {
 //
 // One-wave workgroup: the LDS executes this wave's ds_write / ds_read in program order, so no
 // s_barrier is needed; only keep the compiler from reordering across these points.
+//
+// WT (array-scan kernels): write-through stores (sc1), which leave no dirty line behind in this XCD's L2. There a path may be
+// ended by a wave on ANOTHER XCD (the launch-end ray pool), whose store of the radiance must not be overwritten later by
+// this L2's write-back of the stale value staged here; with sc1 the order of the two stores in memory is the order in which
+// they were acknowledged (s_waitcnt vmcnt(0)), and the kernel publishes a ray only behind that wait.
+template <bool WT = false>
 __device__ __forceinline__ void flush_stage(const float *__restrict__ src, float *__restrict__ dst, uint32_t n_items, int lane) {
 	asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 	const uint32_t n = n_items * 3u, n4 = n >> 2;
 	const float4 *__restrict__ s4 = reinterpret_cast<const float4 *>(src);
 	float4 *__restrict__ d4 = reinterpret_cast<float4 *>(dst);
-	for (uint32_t i = (uint32_t)lane; i < n4; i += 64u) d4[i] = s4[i];
-	for (uint32_t f = (n4 << 2) + (uint32_t)lane; f < n; f += 64u) dst[f] = src[f];
+	if (WT) {
+		typedef float f4v __attribute__((ext_vector_type(4)));
+		for (uint32_t i = (uint32_t)lane; i < n4; i += 64u) {
+			const float4 q = s4[i];
+			f4v v;
+			v.x = q.x, v.y = q.y, v.z = q.z, v.w = q.w;
+			asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(d4 + i), "v"(v) : "memory");
+		}
+		for (uint32_t f = (n4 << 2) + (uint32_t)lane; f < n; f += 64u)
+			__hip_atomic_store(reinterpret_cast<uint32_t *>(dst) + f, dm_f2u(src[f]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+	} else {
+		for (uint32_t i = (uint32_t)lane; i < n4; i += 64u) d4[i] = s4[i];
+		for (uint32_t f = (n4 << 2) + (uint32_t)lane; f < n; f += 64u) dst[f] = src[f];
+	}
 	asm volatile("" ::: "memory");
 }
 
@@ -983,7 +1001,7 @@ struct Stage {
 
 // A path has ended with radiance c: into its sub-job's staging slot if that sub-job is still staged,
 // else (its buffer was needed and written out meanwhile) straight to HBM. f0 / f1 report which.
-template <uint32_t SUB>
+template <uint32_t SUB, bool WT = false>
 __device__ __forceinline__ void deliver(const Stage &st, float *__restrict__ stage, float *__restrict__ radiance, uint32_t item, f3 c, bool &f0, bool &f1 SRT_RC_PARAM) {
 	const uint32_t d0 = item - st.base0, d1 = item - st.base1;
 	if (d0 < st.total0) {
@@ -1006,14 +1024,15 @@ __device__ __forceinline__ void deliver(const Stage &st, float *__restrict__ sta
 		f3v v;
 		v.x = c.x, v.y = c.y, v.z = c.z;
 		float *g = radiance + 3ull * item;
-		asm volatile("global_store_dwordx3 %0, %1, off" : : "v"(g), "v"(v) : "memory");
+		if (WT) asm volatile("global_store_dwordx3 %0, %1, off sc1" : : "v"(g), "v"(v) : "memory"); // (flush_stage)
+		else asm volatile("global_store_dwordx3 %0, %1, off" : : "v"(g), "v"(v) : "memory");
 	}
 }
 
 // Evaluate the sky for the first n queued escapes (n <= 64), one per lane, and finish their
 // paths: mask *= sky; color += mask (render.cl:464-465). Called with all 64 lanes in
 // wave-uniform control flow.
-template <uint32_t SUB>
+template <uint32_t SUB, bool WT = false>
 __device__ __forceinline__ void resolve_ring(const TraceParams &p, const float *__restrict__ ring, uint32_t n, Stage &st, float *__restrict__ stage, int lane SRT_RC_PARAM) {
 	asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 	bool f0 = false, f1 = false;
@@ -1026,7 +1045,7 @@ __device__ __forceinline__ void resolve_ring(const TraceParams &p, const float *
 		const uint32_t item = dm_f2u(ring[9 * RC + lane]);
 		m = m * sky_box(p, d);
 		c = c + m;
-		deliver<SUB>(st, stage, p.radiance, item, c, f0, f1 SRT_RC_ARG);
+		deliver<SUB, WT>(st, stage, p.radiance, item, c, f0, f1 SRT_RC_ARG);
 	}
 	st.pend0 -= (uint32_t)__popcll(ballot64(f0));
 	st.pend1 -= (uint32_t)__popcll(ballot64(f1));
@@ -1102,10 +1121,9 @@ __global__ __launch_bounds__(64, USE_BVH ? SRT_TRACE_WAVES_PER_SIMD_BVH : HAS_MO
 	// radiances up per pixel in sample order.
 	const uint32_t total_items = (uint32_t)p.total_items;
 	const uint32_t nbs = p.batch_samples;
-	// (the work cursor counts chunks)
-	const uint32_t n_chunks = p.n_chunks;
+	const unsigned long long own_chunks_end = (unsigned long long)gridDim.x * p.job_items;
 	uint32_t chunk_cur = 0, chunk_end = 0; // wave-uniform
-	if (blockIdx.x < n_chunks) {
+	if ((unsigned long long)blockIdx.x * p.job_items < (unsigned long long)total_items) {
 		chunk_cur = blockIdx.x * p.job_items;
 		chunk_end = (total_items - chunk_cur < p.job_items) ? total_items : chunk_cur + p.job_items;
 	}
@@ -1134,10 +1152,22 @@ __global__ __launch_bounds__(64, USE_BVH ? SRT_TRACE_WAVES_PER_SIMD_BVH : HAS_MO
 	// (write-through), loads bypass the vector L1 (a slot is reused, and the L1 keeps no track of this CU's own stores) and
 	// wait for the wave's stores first (REFILL below).
 	constexpr bool SUSPEND = HAS_MODELS && (!USE_BVH || SRT_BVH_SUSPEND);
+	constexpr bool WT = SUSPEND; // radiances leave through write-through stores (flush_stage)
 	constexpr uint32_t SQ = (uint32_t)SRT_SQ_CAP, PK = (uint32_t)SRT_PK_CAP;
-	float *__restrict__ sq_base = SUSPEND ? const_cast<float *>((const float *)SRT_COLD(p).scan_queue) + (size_t)blockIdx.x * (size_t)SRT_SCAN_QUEUE_FLOATS : nullptr;
+	float *__restrict__ sq_base = SUSPEND ? const_cast<float *>((const float *)SRT_COLD(p).scan_queue) + (size_t)SRT_POOL_CTL_WORDS + SRT_POOL_REC_FLOATS + (size_t)blockIdx.x * (size_t)SRT_SCAN_QUEUE_FLOATS : nullptr;
 	float *__restrict__ pk = sq_base + 2u * 20u * SQ;
 	uint32_t sq_count0 = 0, sq_count1 = 0, pk_count = 0; // wave-uniform
+	// The END of a launch: a wave that has run out of camera rays holds a remainder of fewer than 64 rays per stack, and every
+	// triangle scan for them would run with idle lanes -- in 5,000 waves at once, and again after each of their bounces. The
+	// waves pool these rays instead (TraceParams.pool_*, one pool per stack): a wave with nothing else left hands its remainder
+	// in, then takes a full block of 64 out if there is one, else leaves. The last wave to leave takes what is left.
+	// Nobody waits for anybody: a block is taken only once its 64 records have been published. Waves of different XCDs meet
+	// here, whose L2s do not see each other's lines: records and radiances go through sc1 (write-through) stores, acknowledged
+	// (s_waitcnt vmcnt(0)) before the agent-scope atomic add that publishes them, and are read with sc1 loads -- no cache
+	// write-back or invalidation, which cost microseconds apiece and would be paid by every wave at every hand-over.
+	const bool use_pool = SUSPEND && SRT_COLD(p).pool_on != 0u;
+	bool pool_leave = false, pool_last = false; // wave-uniform: this wave has signed off / is the last one and clears the pool
+	uint32_t w_pool_taken = 0, w_pool_given = 0, w_pool_last_taken = 0; // diagnostics: blocks taken out, records handed in, blocks taken as the last wave
 	uint32_t ring_count = 0, hq_head = 0, hq_count = 0;                        // wave-uniform
 
 	f3 org = mk(0.f, 0.f, 0.f), dir = mk(0.f, 0.f, 0.f), mask = mk(1.f, 1.f, 1.f), color = mk(0.f, 0.f, 0.f);
@@ -1373,7 +1403,7 @@ __global__ __launch_bounds__(64, USE_BVH ? SRT_TRACE_WAVES_PER_SIMD_BVH : HAS_MO
 			const uint32_t n_miss = (uint32_t)__popcll(mm);
 			const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mm, 0u));
 			if (ring_count + n_miss > RC) { // does not fit: the sky lookups of what is queued first (ring_count lanes busy)
-				resolve_ring<SUB>(p, ring, ring_count, st, stage, lane SRT_RC_ARG);
+				resolve_ring<SUB, WT>(p, ring, ring_count, st, stage, lane SRT_RC_ARG);
 				ring_count = 0;
 			}
 			if (RC == 64u) {
@@ -1400,7 +1430,7 @@ __global__ __launch_bounds__(64, USE_BVH ? SRT_TRACE_WAVES_PER_SIMD_BVH : HAS_MO
 					ring_count += take;
 					done += take;
 					if (done < n_miss) {
-						resolve_ring<SUB>(p, ring, ring_count, st, stage, lane SRT_RC_ARG);
+						resolve_ring<SUB, WT>(p, ring, ring_count, st, stage, lane SRT_RC_ARG);
 						ring_count = 0;
 					}
 				}
@@ -1597,7 +1627,7 @@ __global__ __launch_bounds__(64, USE_BVH ? SRT_TRACE_WAVES_PER_SIMD_BVH : HAS_MO
 		if (any64(fin)) {
 			bool f0 = false, f1 = false;
 			SRT_REGION(HANDIN);
-			if (fin) deliver<SUB>(st, stage, p.radiance, item, color, f0, f1 SRT_RC_ARG);
+			if (fin) deliver<SUB, WT>(st, stage, p.radiance, item, color, f0, f1 SRT_RC_ARG);
 			const uint32_t n0 = (uint32_t)__popcll(ballot64(f0)), n1 = (uint32_t)__popcll(ballot64(f1));
 			st.pend0 -= n0, st.pend1 -= n1;
 			if (SRT_DIAG_ON) w_orphans += (uint32_t)__popcll(ballot64(fin)) - n0 - n1;
@@ -1614,9 +1644,134 @@ __global__ __launch_bounds__(64, USE_BVH ? SRT_TRACE_WAVES_PER_SIMD_BVH : HAS_MO
 			// lanes hold at this point -- bounced or new, about to set out -- are parked and come back into lanes that fall free.
 			// At the very end (no camera ray left, nothing else under way) the fuller stack is taken back as it is.
 			const bool full0 = sq_count0 >= (uint32_t)SRT_SCAN_FULL, full1 = sq_count1 >= (uint32_t)SRT_SCAN_FULL;
-			const bool rest = queue_dry && n_active == 0u && hq_count == 0u && pk_count == 0u && (sq_count0 | sq_count1) != 0u;
+			const bool tail = queue_dry && n_active == 0u && hq_count == 0u && pk_count == 0u;
 			auto ld = [&](const float *a) { return dm_u2f(__hip_atomic_load(reinterpret_cast<const uint32_t *>(a), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)); };
-			if ((full0 || full1 || rest) && pk_count + n_active <= PK) {
+			bool took_pool = false;
+			if (use_pool && tail && !full0 && !full1 && !pool_leave) {
+				SRT_REGION(REFILL_POOL);
+				constexpr uint32_t NB = (uint32_t)SRT_POOL_BLOCKS, NF = USE_BVH ? 20u : 19u;
+				uint32_t *__restrict__ ctl = reinterpret_cast<uint32_t *>(SRT_COLD(p).scan_queue); // [0,1] records reserved, [2,3] blocks taken, [4] waves gone, [5,6] permits, [16 + stack * NB + block] records published
+				float *__restrict__ prec = SRT_COLD(p).scan_queue + SRT_POOL_CTL_WORDS; // [stack][block][field][64]
+				if (!pool_last && (sq_count0 | sq_count1) != 0u) {
+					// Whoever ends these paths stores their radiance straight to HBM: this wave's staged radiances -- stale values
+					// in those paths' places -- must be out before the rays are published (flush; fence; publish).
+					if (ring_count != 0u) {
+						resolve_ring<SUB, WT>(p, ring, ring_count, st, stage, lane SRT_RC_ARG);
+						ring_count = 0;
+					}
+					if (st.total0 != 0u) flush_stage<WT>(stage, p.radiance + 3ull * st.base0, st.total0, lane);
+					if (st.total1 != 0u) flush_stage<WT>(stage + SUB * 3u, p.radiance + 3ull * st.base1, st.total1, lane);
+					st.total0 = 0u, st.pend0 = 0u, st.total1 = 0u, st.pend1 = 0u;
+					asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // (also: this wave's own stack records have arrived)
+					for (uint32_t sid = 0; sid < 2u; sid++) {
+						const uint32_t k = sid ? sq_count1 : sq_count0;
+						if (k == 0u) continue;
+						uint32_t base = 0;
+						if (lane == 0) base = __hip_atomic_fetch_add(ctl + sid, k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+						base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+						const uint32_t room = base < NB * 64u ? NB * 64u - base : 0u;
+						const uint32_t d = k < room ? k : room; // a full pool: the rays beyond stay with this wave
+						const float *__restrict__ src = sq_base + sid * (20u * SQ);
+						for (uint32_t r = (uint32_t)lane; r < d; r += 64u) {
+							const uint32_t e = k - 1u - r, g = base + r;
+							uint32_t *__restrict__ dst = reinterpret_cast<uint32_t *>(prec) + ((size_t)sid * NB + (g >> 6)) * (20u * 64u) + (g & 63u);
+							for (uint32_t f = 0; f < NF; f++) __hip_atomic_store(dst + f * 64u, dm_f2u(ld(src + f * SQ + e)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+						}
+						// records (and the radiances above) have been acknowledged by memory before they are published: lane j adds,
+						// for the j-th block the records went into, how many went there (d <= 190: four blocks at most)
+						asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+						if (d != 0u) {
+							const uint32_t b0 = base >> 6, bj = b0 + (uint32_t)lane;
+							const uint32_t lo = bj * 64u > base ? bj * 64u : base, hi = (bj + 1u) * 64u < base + d ? (bj + 1u) * 64u : base + d;
+							if ((uint32_t)lane < 4u && hi > lo) (void)__hip_atomic_fetch_add(ctl + 16u + sid * NB + bj, hi - lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+							// a permit for every block this reservation has completed (its last place reserved)
+							const uint32_t done = ((base + d) >> 6) - b0;
+							if (lane == 0 && done != 0u) (void)__hip_atomic_fetch_add(ctl + 5u + sid, done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+						}
+						if (sid) sq_count1 = k - d;
+						else sq_count0 = k - d;
+						w_pool_given += d;
+					}
+				}
+				const bool kept = (sq_count0 | sq_count1) != 0u; // (a full pool, or the last wave's own)
+				uint32_t got_sid = 2u, got_blk = 0u, got_cnt = 0u;
+				if (lane == 0 && !pool_last) {
+					// One permit per block whose 64 places have all been reserved (ctl[5 + stack], signed); a wave that gets one
+					// draws the number of its block from the head counter. No compare-and-swap loop: with thousands of waves at one
+					// counter every success makes all the others fail and try again (measured: 2,100 rounds per attempt).
+					for (uint32_t sid = 0; sid < 2u && got_sid == 2u; sid++) {
+						if ((int)__hip_atomic_load(ctl + 5u + sid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) <= 0) continue;
+						if ((int)__hip_atomic_fetch_sub(ctl + 5u + sid, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > 0) {
+							got_sid = sid, got_cnt = 64u;
+							got_blk = __hip_atomic_fetch_add(ctl + 2u + sid, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+						} else {
+							(void)__hip_atomic_fetch_add(ctl + 5u + sid, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+						}
+					}
+				}
+				got_sid = (uint32_t)__builtin_amdgcn_readfirstlane((int)got_sid);
+				if (got_sid == 2u && !kept && !pool_last) {
+					uint32_t gone = 0;
+					asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // (what this wave published has arrived)
+					if (lane == 0) gone = __hip_atomic_fetch_add(ctl + 4u, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+					gone = (uint32_t)__builtin_amdgcn_readfirstlane((int)gone);
+					if (gone == gridDim.x - 1u) pool_last = true; // every other wave has published what it had and is gone
+					else pool_leave = true;
+				}
+				if (got_sid == 2u && !kept && pool_last) {
+					if (lane == 0) {
+						for (uint32_t sid = 0; sid < 2u && got_sid == 2u; sid++) {
+							const uint32_t h = __hip_atomic_load(ctl + 2u + sid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+							uint32_t res = __hip_atomic_load(ctl + sid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+							res = res < NB * 64u ? res : NB * 64u;
+							if (h < NB && res > h * 64u) {
+								got_sid = sid, got_blk = h, got_cnt = res - h * 64u < 64u ? res - h * 64u : 64u;
+								__hip_atomic_store(ctl + 2u + sid, h + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+							}
+						}
+					}
+					got_sid = (uint32_t)__builtin_amdgcn_readfirstlane((int)got_sid);
+				}
+				if (got_sid != 2u) {
+					got_blk = (uint32_t)__builtin_amdgcn_readfirstlane((int)got_blk);
+					got_cnt = (uint32_t)__builtin_amdgcn_readfirstlane((int)got_cnt);
+					// All places of the block are reserved; the waves that reserved the last ones may still be writing (straight-line
+					// code between their reservation and its publication: microseconds). Bounded all the same.
+					uint32_t spins = 0;
+					while (__hip_atomic_load(ctl + 16u + got_sid * NB + got_blk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < got_cnt) {
+						__builtin_amdgcn_s_sleep(8);
+						if (++spins > (1u << 22)) {
+							if (lane == 0) atomicAdd((unsigned long long *)SRT_COLD(p).counters + SRT_CTR_WATCHDOG, 1ull);
+							got_cnt = 0u; // (the launch is reported as failed)
+							break;
+						}
+					}
+					const float *__restrict__ src = prec + ((size_t)got_sid * NB + got_blk) * (20u * 64u) + (uint32_t)lane;
+					active = (uint32_t)lane < got_cnt;
+					if (active) {
+						org = mk(ld(src + 0 * 64), ld(src + 1 * 64), ld(src + 2 * 64));
+						dir = mk(ld(src + 3 * 64), ld(src + 4 * 64), ld(src + 5 * 64));
+						mask = mk(ld(src + 6 * 64), ld(src + 7 * 64), ld(src + 8 * 64));
+						color = mk(ld(src + 9 * 64), ld(src + 10 * 64), ld(src + 11 * 64));
+						seed = dm_f2u(ld(src + 12 * 64)), bounce = (int)dm_f2u(ld(src + 13 * 64)), item = dm_f2u(ld(src + 14 * 64));
+						tmin = ld(src + 15 * 64), best = (int)dm_f2u(ld(src + 16 * 64)), best_tri = dm_f2u(ld(src + 17 * 64));
+						pos = dm_f2u(ld(src + 18 * 64));
+						if (USE_BVH) best_j = dm_f2u(ld(src + 19 * 64));
+						resumed = true;
+					}
+					asm volatile("" ::: "memory");
+					n_active = got_cnt;
+					freeb = ballot64(!active);
+					n_free = 64u - got_cnt;
+					took_pool = true;
+					w_pool_taken++;
+					if (pool_last) w_pool_last_taken++;
+				}
+			}
+			const bool rest = tail && !took_pool && (sq_count0 | sq_count1) != 0u;
+			if (took_pool) {
+				// (the wave is full of rays from the pool)
+			} else if ((full0 || full1 || rest) && pk_count + n_active <= PK) {
 				SRT_REGION(REFILL_SCANQ);
 				if (n_active != 0u) {
 					const unsigned long long ab = ~freeb;
@@ -1695,29 +1850,28 @@ __global__ __launch_bounds__(64, USE_BVH ? SRT_TRACE_WAVES_PER_SIMD_BVH : HAS_MO
 						// their way (pend != 0) deliver to HBM themselves when they end (deliver() orders their stores
 						// behind this one).
 						const uint32_t o_pend = o ? st.pend1 : st.pend0;
-						flush_stage(stage + o * SUB * 3u, p.radiance + 3ull * (o ? st.base1 : st.base0), o_total, lane);
+						flush_stage<WT>(stage + o * SUB * 3u, p.radiance + 3ull * (o ? st.base1 : st.base0), o_total, lane);
 						if (SRT_DIAG_ON && o_pend != 0u) w_evict++;
 						if (o) st.total1 = 0u, st.pend1 = 0u;
 						else st.total0 = 0u, st.pend0 = 0u;
 					}
 					if (chunk_cur == chunk_end) {
 						SRT_REGION(REFILL_CURSOR);
-						unsigned long long k = n_chunks; // ordinal of the next chunk
-						if (gridDim.x < n_chunks) { // else every chunk is some wave's first: nothing to ask the cursor for
-							unsigned long long got_k = 0;
-							if (lane == 0) got_k = atomicAdd((unsigned long long *)SRT_COLD(p).queue, 1ull);
+						unsigned long long start = total_items;
+						if (own_chunks_end < (unsigned long long)total_items) { // else every chunk is some wave's first: nothing to ask the cursor for
+							if (lane == 0) start = atomicAdd((unsigned long long *)SRT_COLD(p).queue, (unsigned long long)SRT_COLD(p).job_items);
 							// lane 0's value as a scalar (wave-uniform control flow: lane 0 is active), so that everything derived from
 							// it -- chunk bounds, sub-job bases -- stays in SGPRs
-							const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)got_k);
-							const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(got_k >> 32));
-							k = (((unsigned long long)hi << 32) | lo) + gridDim.x;
+							const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)start);
+							const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(start >> 32));
+							start = (((unsigned long long)hi << 32) | lo) + own_chunks_end;
 						}
-						if (k >= (unsigned long long)n_chunks) {
+						if (start >= (unsigned long long)total_items) {
 							queue_dry = true;
 							break;
 						}
+						chunk_cur = (uint32_t)start;
 						const uint32_t job_items = SRT_COLD(p).job_items;
-						chunk_cur = (uint32_t)k * job_items;
 						chunk_end = (total_items - chunk_cur < job_items) ? total_items : chunk_cur + job_items;
 					}
 					const uint32_t left = chunk_end - chunk_cur;
@@ -1800,7 +1954,7 @@ __global__ __launch_bounds__(64, USE_BVH ? SRT_TRACE_WAVES_PER_SIMD_BVH : HAS_MO
 		SRT_CLK(5);
 		SRT_REGION(LOOP_TAIL);
 		if (n_active == 0u && hq_count == 0u && (sq_count0 | sq_count1 | pk_count) == 0u) {
-			if (queue_dry) break;
+			if (queue_dry && (!use_pool || pool_leave || pool_last)) break; // (with a pool: not before the wave has signed off, REFILL above)
 			// Bounded: a wave that spins here without ever getting work leaves with the watchdog counter set instead of hanging.
 			if (++idle_spins > (1u << 20)) {
 				if (lane == 0) atomicAdd((unsigned long long *)SRT_COLD(p).counters + SRT_CTR_WATCHDOG, 1ull);
@@ -1812,9 +1966,9 @@ __global__ __launch_bounds__(64, USE_BVH ? SRT_TRACE_WAVES_PER_SIMD_BVH : HAS_MO
 	}
 	// queue dry, no lane active, nothing parked: whatever is still staged is complete
 	SRT_REGION(EPILOGUE);
-	if (ring_count != 0u) resolve_ring<SUB>(p, ring, ring_count, st, stage, lane SRT_RC_ARG);
-	if (st.total0 != 0u) flush_stage(stage, p.radiance + 3ull * st.base0, st.total0, lane);
-	if (st.total1 != 0u) flush_stage(stage + SUB * 3u, p.radiance + 3ull * st.base1, st.total1, lane);
+	if (ring_count != 0u) resolve_ring<SUB, WT>(p, ring, ring_count, st, stage, lane SRT_RC_ARG);
+	if (st.total0 != 0u) flush_stage<WT>(stage, p.radiance + 3ull * st.base0, st.total0, lane);
+	if (st.total1 != 0u) flush_stage<WT>(stage + SUB * 3u, p.radiance + 3ull * st.base1, st.total1, lane);
 
 	// per-wave counters: this wave's own 64-byte line, no atomics (device_types.h)
 	unsigned long long t3 = COUNT_TRIS ? n_tri : w_scans, t4 = COUNT_TRIS ? n_tri_u : w_scan_lanes;
@@ -1835,6 +1989,9 @@ __global__ __launch_bounds__(64, USE_BVH ? SRT_TRACE_WAVES_PER_SIMD_BVH : HAS_MO
 		} else if (SUSPEND) { // diagnostics in the slots the instrumented variant uses for triangle counts
 			w[8] += t3;
 			w[9] += t4;
+#ifndef SRT_PHASE_CLOCK
+			w[10] += w_pool_taken, w[11] += w_pool_given, w[12] += (unsigned long long)w_pool_taken * w_pool_taken, w[13] += w_pool_last_taken;
+#endif
 		}
 		w[5] += (unsigned long long)w_orphans + ((unsigned long long)w_evict << 40); // diagnostics (srt_debug_counters)
 		w[6] += w_iter;

@@ -292,7 +292,9 @@ class Tracer:
                 "iterations": v[6], "shade_phases": v[7], "waves_per_cu": v[8], "grid": v[9],
                 "phase_cycles": dict(zip(("extend", "ring", "shade", "park", "deliver", "refill", "head", "kernel"), v[10:18])),
                 # array-scan kernels without -DSRT_PHASE_CLOCK reuse the first two clock slots: big-model scans and the lanes in them
-                "scans": v[10], "scan_lanes": v[11]}
+                "scans": v[10], "scan_lanes": v[11],
+                # ... and the next four: the launch-end ray pool (blocks taken, records handed in, sum of squares of the blocks a wave took, blocks the last wave took)
+                "pool_taken": v[12], "pool_given": v[13], "pool_taken_sq": v[14], "pool_last_taken": v[15]}
 
     def debug_region_counters(self):
         """[(waves, lanes)] per region of SRT_REGION_LIST for a -DSRT_REGION_COUNT build; [] for the product build."""

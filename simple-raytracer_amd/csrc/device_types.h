@@ -129,7 +129,8 @@ struct TraceParams {
 	uint32_t width_magic, width_shift; /* n / width = (mulhi(n, magic) + n) >> shift for n < 2^31 (srt_magic_u31) */
 	uint32_t rpb_magic, rpb_shift;     /* the same for rows_per_block */
 	uint32_t nbs_magic16;              /* n / batch_samples = (n * magic16) >> 16 for n < 256, when batch_samples < 128 (else unused) */
-	uint32_t pool_on;                  /* array scan, end of a launch: the waves' leftover rays are pooled (kernels.hip; 0 = every wave scans its own remainder) */
+	uint32_t pool_blocks;              /* array scan, end of a launch: the waves' leftover rays are pooled, in at most this many blocks of 64 per stack
+	                                      (kernels.hip; <= SRT_POOL_BLOCKS; 0 = no pool, every wave scans its own remainder) */
 	int32_t unit_materials;            /* the device materials hold bernoulli() thresholds in place of metallic / specular / transmittance */
 	int32_t all_materials_ok;          /* no shape with a negative material index: the closest shape is a hit without looking its material up (render.cl:404) */
 };

@@ -1065,7 +1065,7 @@ __device__ __forceinline__ void resolve_ring(const TraceParams &p, const float *
 #define SRT_TRACE_WAVES_PER_SIMD_MODELS 5
 #endif
 #ifndef SRT_TRACE_WAVES_PER_SIMD_BVH
-#define SRT_TRACE_WAVES_PER_SIMD_BVH 4
+#define SRT_TRACE_WAVES_PER_SIMD_BVH 5 // (4: configs[2] 42.0 ms, configs[4] 38.0 ms; 5: 40.8 / 36.5 -- the walk waits for memory, a fifth wave fills the gaps)
 #endif
 
 // HAS_MODELS = false compiles every AABB / triangle / mesh-normal path out: scenes of
@@ -1165,7 +1165,7 @@ __global__ __launch_bounds__(64, USE_BVH ? SRT_TRACE_WAVES_PER_SIMD_BVH : HAS_MO
 	// here, whose L2s do not see each other's lines: records and radiances go through sc1 (write-through) stores, acknowledged
 	// (s_waitcnt vmcnt(0)) before the agent-scope atomic add that publishes them, and are read with sc1 loads -- no cache
 	// write-back or invalidation, which cost microseconds apiece and would be paid by every wave at every hand-over.
-	const bool use_pool = SUSPEND && SRT_COLD(p).pool_on != 0u;
+	const bool use_pool = SUSPEND && SRT_COLD(p).pool_blocks != 0u;
 	bool pool_leave = false, pool_last = false; // wave-uniform: this wave has signed off / is the last one and clears the pool
 	uint32_t w_pool_taken = 0, w_pool_given = 0, w_pool_last_taken = 0; // diagnostics: blocks taken out, records handed in, blocks taken as the last wave
 	uint32_t ring_count = 0, hq_head = 0, hq_count = 0;                        // wave-uniform
@@ -1649,7 +1649,8 @@ __global__ __launch_bounds__(64, USE_BVH ? SRT_TRACE_WAVES_PER_SIMD_BVH : HAS_MO
 			bool took_pool = false;
 			if (use_pool && tail && !full0 && !full1 && !pool_leave) {
 				SRT_REGION(REFILL_POOL);
-				constexpr uint32_t NB = (uint32_t)SRT_POOL_BLOCKS, NF = USE_BVH ? 20u : 19u;
+				constexpr uint32_t NF = USE_BVH ? 20u : 19u;
+				const uint32_t NB = SRT_COLD(p).pool_blocks; // blocks per stack (<= SRT_POOL_BLOCKS, which the layout is made for)
 				uint32_t *__restrict__ ctl = reinterpret_cast<uint32_t *>(SRT_COLD(p).scan_queue); // [0,1] records reserved, [2,3] blocks taken, [4] waves gone, [5,6] permits, [16 + stack * NB + block] records published
 				float *__restrict__ prec = SRT_COLD(p).scan_queue + SRT_POOL_CTL_WORDS; // [stack][block][field][64]
 				if (!pool_last && (sq_count0 | sq_count1) != 0u) {
@@ -1674,7 +1675,7 @@ __global__ __launch_bounds__(64, USE_BVH ? SRT_TRACE_WAVES_PER_SIMD_BVH : HAS_MO
 						const float *__restrict__ src = sq_base + sid * (20u * SQ);
 						for (uint32_t r = (uint32_t)lane; r < d; r += 64u) {
 							const uint32_t e = k - 1u - r, g = base + r;
-							uint32_t *__restrict__ dst = reinterpret_cast<uint32_t *>(prec) + ((size_t)sid * NB + (g >> 6)) * (20u * 64u) + (g & 63u);
+							uint32_t *__restrict__ dst = reinterpret_cast<uint32_t *>(prec) + ((size_t)sid * SRT_POOL_BLOCKS + (g >> 6)) * (20u * 64u) + (g & 63u);
 							for (uint32_t f = 0; f < NF; f++) __hip_atomic_store(dst + f * 64u, dm_f2u(ld(src + f * SQ + e)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 						}
 						// records (and the radiances above) have been acknowledged by memory before they are published: lane j adds,
@@ -1683,7 +1684,7 @@ __global__ __launch_bounds__(64, USE_BVH ? SRT_TRACE_WAVES_PER_SIMD_BVH : HAS_MO
 						if (d != 0u) {
 							const uint32_t b0 = base >> 6, bj = b0 + (uint32_t)lane;
 							const uint32_t lo = bj * 64u > base ? bj * 64u : base, hi = (bj + 1u) * 64u < base + d ? (bj + 1u) * 64u : base + d;
-							if ((uint32_t)lane < 4u && hi > lo) (void)__hip_atomic_fetch_add(ctl + 16u + sid * NB + bj, hi - lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+							if ((uint32_t)lane < 4u && hi > lo) (void)__hip_atomic_fetch_add(ctl + 16u + sid * (uint32_t)SRT_POOL_BLOCKS + bj, hi - lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 							// a permit for every block this reservation has completed (its last place reserved)
 							const uint32_t done = ((base + d) >> 6) - b0;
 							if (lane == 0 && done != 0u) (void)__hip_atomic_fetch_add(ctl + 5u + sid, done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1738,7 +1739,7 @@ __global__ __launch_bounds__(64, USE_BVH ? SRT_TRACE_WAVES_PER_SIMD_BVH : HAS_MO
 					// All places of the block are reserved; the waves that reserved the last ones may still be writing (straight-line
 					// code between their reservation and its publication: microseconds). Bounded all the same.
 					uint32_t spins = 0;
-					while (__hip_atomic_load(ctl + 16u + got_sid * NB + got_blk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < got_cnt) {
+					while (__hip_atomic_load(ctl + 16u + got_sid * (uint32_t)SRT_POOL_BLOCKS + got_blk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < got_cnt) {
 						__builtin_amdgcn_s_sleep(8);
 						if (++spins > (1u << 22)) {
 							if (lane == 0) atomicAdd((unsigned long long *)SRT_COLD(p).counters + SRT_CTR_WATCHDOG, 1ull);
@@ -1746,7 +1747,7 @@ __global__ __launch_bounds__(64, USE_BVH ? SRT_TRACE_WAVES_PER_SIMD_BVH : HAS_MO
 							break;
 						}
 					}
-					const float *__restrict__ src = prec + ((size_t)got_sid * NB + got_blk) * (20u * 64u) + (uint32_t)lane;
+					const float *__restrict__ src = prec + ((size_t)got_sid * SRT_POOL_BLOCKS + got_blk) * (20u * 64u) + (uint32_t)lane;
 					active = (uint32_t)lane < got_cnt;
 					if (active) {
 						org = mk(ld(src + 0 * 64), ld(src + 1 * 64), ld(src + 2 * 64));

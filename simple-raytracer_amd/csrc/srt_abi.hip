@@ -1008,7 +1008,11 @@ int srt_trace(srt_tracer *t, const srt_render_data *options) {
 
 	if (t->num_models > 0 && (!t->bvh_active || srt_bvh_suspends()) && srt_scan_queue_in_hbm()) // one block per persistent wave, two sets (overlapping batches)
 		SRT_HIP(t, t->scan_queue.reserve(2 * SRT_SCAN_SET_FLOATS(slots))); // (per set: the pool's 84 MB and 46 KB per wave, 236 MB on 256 CUs)
-	const bool use_pool = t->scan_queue.ptr && !getenv("SRT_NO_SCAN_POOL");
+	uint32_t pool_blocks = t->scan_queue.ptr && !getenv("SRT_NO_SCAN_POOL") ? (uint32_t)SRT_POOL_BLOCKS : 0u;
+	if (const char *env = getenv("SRT_POOL_BLOCKS")) { // tests: a pool that overflows
+		const int v = atoi(env);
+		if (v >= 0 && (uint32_t)v < pool_blocks) pool_blocks = (uint32_t)v;
+	}
 
 	ReduceParams rp;
 	rp.radiance = t->radiance.ptr;
@@ -1062,7 +1066,7 @@ int srt_trace(srt_tracer *t, const srt_render_data *options) {
 		p.queue = t->counters.ptr + (par ? SRT_CTR_QUEUE2 : SRT_CTR_QUEUE);
 		p.wave_counters = t->wave_counters.ptr + (size_t)par * SRT_WAVE_CTR_SLOTS * SRT_WAVE_CTR_STRIDE;
 		p.scan_queue = t->scan_queue.ptr ? t->scan_queue.ptr + (size_t)par * SRT_SCAN_SET_FLOATS(slots) : nullptr;
-		p.pool_on = use_pool ? 1u : 0u;
+		p.pool_blocks = pool_blocks;
 		if (overlap && b >= 2) SRT_HIP(t, hipStreamWaitEvent(ts, t->ev_batch_reduced[par], 0)); // batch b - 2 has been summed up
 		const uint32_t s0 = b * batch;
 		const uint32_t nbs = (uint32_t)ns - s0 < batch ? (uint32_t)ns - s0 : batch;
@@ -1102,7 +1106,7 @@ int srt_trace(srt_tracer *t, const srt_render_data *options) {
 		const unsigned long long waves_needed = (p.total_items + 63ull) / 64ull;
 		const int num_waves = (int)(waves_needed < slots_b ? waves_needed : slots_b);
 		SRT_HIP(t, hipMemsetAsync(p.queue, 0, sizeof(unsigned long long), ts));
-		if (p.pool_on) SRT_HIP(t, hipMemsetAsync(p.scan_queue, 0, (size_t)SRT_POOL_CTL_WORDS * sizeof(uint32_t), ts));
+		if (p.pool_blocks) SRT_HIP(t, hipMemsetAsync(p.scan_queue, 0, (size_t)SRT_POOL_CTL_WORDS * sizeof(uint32_t), ts));
 		SRT_HIP(t, hipEventRecord(t->ev_k[2 * b], ts));
 		t->last_grid = num_waves;
 		srt_launch_trace(p, t->count_tris, num_waves, ts);

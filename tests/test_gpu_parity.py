@@ -84,6 +84,29 @@ def test_mesh_scene_968_triangles_vs_oracle(T, sky, oracle):
     t.close()
 
 
+def test_scan_pool_sizes_are_invisible(T, sky, oracle, monkeypatch):
+    """Array scan: at the end of a launch the waves pool the rays left in their scan stacks (kernels.hip). Whatever the pool
+    holds -- nothing at all, one block of 64 rays (it overflows at once: the waves keep what does not fit), seven blocks, the
+    full size -- and however many launches (sample batches) there are, the canvas is the oracle's bit for bit."""
+    shapes, tris, mats = S.mesh_scene(2)
+    rd = R.render_data(160, 90, 6, 10, camera_to_world=S.default_camera(), time=777)
+    g = dict(shapes=shapes, tris=tris, mats=mats, rd=rd, sd=R.scene_data(len(shapes)))
+    want = oracle.render(rd, g["sd"], shapes, tris, mats, sky)
+    for env, val in ((None, None), ("SRT_POOL_BLOCKS", "1"), ("SRT_POOL_BLOCKS", "7"), ("SRT_NO_SCAN_POOL", "1")):
+        if env:
+            monkeypatch.setenv(env, val)
+        for budget in (0, 160 * 90 * 12 * 2):
+            t = make_tracer(T, g, sky)
+            if budget:
+                t.set_radiance_budget(budget)  # three launches of two samples
+            t.trace()
+            assert bits_equal(t.read_canvas(), want), f"{env}={val}, budget {budget}"
+            assert t.counters()["watchdog"] == 0
+            t.close()
+        if env:
+            monkeypatch.delenv(env)
+
+
 def test_100k_triangle_mesh_vs_oracle(T, sky, oracle):
     """configs[4] geometry (one 99,904-triangle flat mesh + plane), tiny canvas so the
     brute-force oracle finishes in seconds."""

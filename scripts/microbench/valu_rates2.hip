@@ -53,6 +53,12 @@
 	X(45, "3 cndmask e32 + 1 v_mul", "v_cndmask_b32 %4, %4, %5, vcc\n v_cndmask_b32 %6, %6, %7, vcc\n v_cndmask_b32 %5, %5, %7, vcc\n v_mul_f32 %2, %2, %3") \
 	X(46, "cndmask e32, s_nop 0 between", "v_cndmask_b32 %4, %0, %1, vcc\n s_nop 0\n v_cndmask_b32 %5, %1, %2, vcc\n s_nop 0\n v_cndmask_b32 %6, %2, %3, vcc\n s_nop 0\n v_cndmask_b32 %7, %3, %0, vcc\n s_nop 0") \
 	X(47, "cndmask e32 sdwa-free src0 const", "v_cndmask_b32 %4, 1.0, %1, vcc\n v_cndmask_b32 %5, 1.0, %2, vcc\n v_cndmask_b32 %6, 1.0, %3, vcc\n v_cndmask_b32 %7, 1.0, %0, vcc") \
+	X(48, "v_pk_fma_f32", "v_pk_fma_f32 %8, %8, %9, %8\n v_pk_fma_f32 %9, %9, %8, %9\n v_pk_fma_f32 %8, %8, %9, %8\n v_pk_fma_f32 %9, %9, %8, %9") \
+	X(49, "v_pk_mul_f32", "v_pk_mul_f32 %8, %8, %9\n v_pk_mul_f32 %9, %9, %8\n v_pk_mul_f32 %8, %8, %9\n v_pk_mul_f32 %9, %9, %8") \
+	X(50, "v_pk_add_f32", "v_pk_add_f32 %8, %8, %9\n v_pk_add_f32 %9, %9, %8\n v_pk_add_f32 %8, %8, %9\n v_pk_add_f32 %9, %9, %8") \
+	X(51, "v_pk_fma_f32 (sgpr pair src)", "v_pk_fma_f32 %8, s[20:21], %9, %8\n v_pk_fma_f32 %9, s[20:21], %8, %9\n v_pk_fma_f32 %8, s[20:21], %9, %8\n v_pk_fma_f32 %9, s[20:21], %8, %9") \
+	X(52, "v_pk_mul_f32 (sgpr pair, neg)", "v_pk_mul_f32 %8, %9, s[20:21] neg_lo:[0,1] neg_hi:[0,1]\n v_pk_mul_f32 %9, %8, s[20:21] neg_lo:[0,1] neg_hi:[0,1]\n v_pk_mul_f32 %8, %9, s[20:21] neg_lo:[0,1] neg_hi:[0,1]\n v_pk_mul_f32 %9, %8, s[20:21] neg_lo:[0,1] neg_hi:[0,1]") \
+	X(53, "v_pk_mul_f32 (op_sel_hi splat)", "v_pk_mul_f32 %8, %8, %9 op_sel_hi:[1,0]\n v_pk_mul_f32 %9, %9, %8 op_sel_hi:[1,0]\n v_pk_mul_f32 %8, %8, %9 op_sel_hi:[1,0]\n v_pk_mul_f32 %9, %9, %8 op_sel_hi:[1,0]") \
 	X(36, "v_add_u32(inline 4)", "v_add_u32 %4, 4, %4\n v_add_u32 %5, 4, %5\n v_add_u32 %6, 4, %6\n v_add_u32 %7, 4, %7")
 
 template <int OP>

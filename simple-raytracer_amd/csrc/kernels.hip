@@ -957,6 +957,17 @@ __device__ __forceinline__ f3 sky_box(const TraceParams &p_live, f3 dir) {
 #define SRT_CLK(i)
 #endif
 
+// Radiance stores are write-through (sc1) in every kernel: measured on the sphere frame at 64 spp (1.59 GB of radiance per
+// launch; profiles/r03_radiance_store_flavours.json), trace-kernel WRITE_SIZE / FETCH_SIZE 3.73 / 2.14 GB with plain stores
+// (a straggler's 12 bytes land in a line that has left the L2: read for ownership, written back whole), 3.04 / 0.26 GB with
+// sc1 -- the kernel time is the same. (A/B: SRT_WT_ALL=0 restores plain stores outside the array scan, which needs sc1;
+// SRT_ORPHAN_STORE picks the straggler's store alone: 0 plain, 1 sc1, 2 nt -- nt is no better than plain.)
+#ifndef SRT_ORPHAN_STORE
+#define SRT_ORPHAN_STORE 0
+#endif
+#ifndef SRT_WT_ALL
+#define SRT_WT_ALL 1
+#endif
 namespace {
 // One wave writes a sub-job's radiances (n items, packed 12-byte items in LDS) to HBM: whole
 // 64-byte lines, 16 B per lane per store. Both sides are 16-byte aligned (sub-jobs start on
@@ -1024,7 +1035,8 @@ __device__ __forceinline__ void deliver(const Stage &st, float *__restrict__ sta
 		f3v v;
 		v.x = c.x, v.y = c.y, v.z = c.z;
 		float *g = radiance + 3ull * item;
-		if (WT) asm volatile("global_store_dwordx3 %0, %1, off sc1" : : "v"(g), "v"(v) : "memory"); // (flush_stage)
+		if (WT || SRT_ORPHAN_STORE == 1) asm volatile("global_store_dwordx3 %0, %1, off sc1" : : "v"(g), "v"(v) : "memory"); // (flush_stage)
+		else if (SRT_ORPHAN_STORE == 2) asm volatile("global_store_dwordx3 %0, %1, off nt" : : "v"(g), "v"(v) : "memory");
 		else asm volatile("global_store_dwordx3 %0, %1, off" : : "v"(g), "v"(v) : "memory");
 	}
 }
@@ -1152,7 +1164,7 @@ __global__ __launch_bounds__(64, USE_BVH ? SRT_TRACE_WAVES_PER_SIMD_BVH : HAS_MO
 	// (write-through), loads bypass the vector L1 (a slot is reused, and the L1 keeps no track of this CU's own stores) and
 	// wait for the wave's stores first (REFILL below).
 	constexpr bool SUSPEND = HAS_MODELS && (!USE_BVH || SRT_BVH_SUSPEND);
-	constexpr bool WT = SUSPEND; // radiances leave through write-through stores (flush_stage)
+	constexpr bool WT = SUSPEND || SRT_WT_ALL; // radiances leave through write-through stores (flush_stage)
 	constexpr uint32_t SQ = (uint32_t)SRT_SQ_CAP, PK = (uint32_t)SRT_PK_CAP;
 	float *__restrict__ sq_base = SUSPEND ? const_cast<float *>((const float *)SRT_COLD(p).scan_queue) + (size_t)SRT_POOL_CTL_WORDS + SRT_POOL_REC_FLOATS + (size_t)blockIdx.x * (size_t)SRT_SCAN_QUEUE_FLOATS : nullptr;
 	float *__restrict__ pk = sq_base + 2u * 20u * SQ;

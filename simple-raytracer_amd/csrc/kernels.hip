@@ -24,8 +24,8 @@
 //    last improving hit survives there, so deferring is exact.
 //  * Triangles are pre-transformed to world space once per scene (srt_prepass_kernel)
 //    in the reference's operation order, removing 63 of ~115 flops per triangle test.
-//  * Model shapes optionally carry a BVH (srt_set_acceleration): a stackless per-lane walk
-//    over skip-linked nodes replaces the array scan, same triangle test, same tie rule.
+//  * Model shapes optionally carry a BVH (srt_set_acceleration): a per-lane, stack-based walk over
+//    four-wide 128-byte blocks (walk_bvh) replaces the array scan, same triangle test, same tie rule.
 //  * No MFMA: nothing here is a contraction. Compiled with -ffp-contract=off; every
 //    float op is an IEEE add/mul/div/sqrt or a detmath.h routine so that results match
 //    the CPU oracle bit for bit (DESIGN.md "Numerics"). The kernel is VALU-issue bound, so

@@ -163,7 +163,9 @@ int srt_reset_counters(srt_tracer *t);
  * radiance themselves, plus (staging buffers written out early << 40); out[6] = iterations of the
  * waves' main loop; out[7] = SHADE phases executed (sums since the last srt_reset_counters); out[8] = persistent
  * waves per CU and out[9] = workgroups of the most recent trace launch; out[10..17] = per-phase wave cycles
- * (extend, sky ring, shade, park, deliver, refill, loop head, whole kernel) of a -DSRT_PHASE_CLOCK build, else 0. */
+ * (extend, sky ring, shade, park, deliver, refill, loop head, whole kernel) of a -DSRT_PHASE_CLOCK build; in the product
+ * build of the array-scan kernels out[10..15] = triangle scans of big models, lanes in them, blocks of 64 rays taken out
+ * of the launch-end ray pool, records handed in to it, sum over waves of (blocks taken)^2, blocks the last wave took; else 0. */
 int srt_debug_counters(srt_tracer *t, uint64_t out[18]);
 /* Development builds with -DSRT_REGION_COUNT only (the product build writes nothing and sets *written = 0): for each
  * region of the trace kernel, in the order of SRT_REGION_LIST (csrc/kernels.hip), {times a wave ran it, lanes that ran it}

@@ -59,6 +59,13 @@
 	X(51, "v_pk_fma_f32 (sgpr pair src)", "v_pk_fma_f32 %8, s[20:21], %9, %8\n v_pk_fma_f32 %9, s[20:21], %8, %9\n v_pk_fma_f32 %8, s[20:21], %9, %8\n v_pk_fma_f32 %9, s[20:21], %8, %9") \
 	X(52, "v_pk_mul_f32 (sgpr pair, neg)", "v_pk_mul_f32 %8, %9, s[20:21] neg_lo:[0,1] neg_hi:[0,1]\n v_pk_mul_f32 %9, %8, s[20:21] neg_lo:[0,1] neg_hi:[0,1]\n v_pk_mul_f32 %8, %9, s[20:21] neg_lo:[0,1] neg_hi:[0,1]\n v_pk_mul_f32 %9, %8, s[20:21] neg_lo:[0,1] neg_hi:[0,1]") \
 	X(53, "v_pk_mul_f32 (op_sel_hi splat)", "v_pk_mul_f32 %8, %8, %9 op_sel_hi:[1,0]\n v_pk_mul_f32 %9, %9, %8 op_sel_hi:[1,0]\n v_pk_mul_f32 %8, %8, %9 op_sel_hi:[1,0]\n v_pk_mul_f32 %9, %9, %8 op_sel_hi:[1,0]") \
+	X(54, "v_div_scale_f32", "v_div_scale_f32 %0, vcc, %0, %1, %0\n v_div_scale_f32 %1, vcc, %1, %2, %1\n v_div_scale_f32 %2, vcc, %2, %3, %2\n v_div_scale_f32 %3, vcc, %3, %0, %3") \
+	X(55, "v_div_fmas_f32", "v_div_fmas_f32 %0, %0, %1, %2\n v_div_fmas_f32 %1, %1, %2, %3\n v_div_fmas_f32 %2, %2, %3, %0\n v_div_fmas_f32 %3, %3, %0, %1") \
+	X(56, "v_div_fixup_f32", "v_div_fixup_f32 %0, %0, %1, %2\n v_div_fixup_f32 %1, %1, %2, %3\n v_div_fixup_f32 %2, %2, %3, %0\n v_div_fixup_f32 %3, %3, %0, %1") \
+	X(57, "v_rcp_f32", "v_rcp_f32 %0, %0\n v_rcp_f32 %1, %1\n v_rcp_f32 %2, %2\n v_rcp_f32 %3, %3") \
+	X(58, "v_fma_f32 (2 vgpr + sgpr)", "v_fma_f32 %0, %0, s20, %1\n v_fma_f32 %1, %1, s20, %2\n v_fma_f32 %2, %2, s20, %3\n v_fma_f32 %3, %3, s20, %0") \
+	X(59, "v_fma_f32 (neg modifier)", "v_fma_f32 %0, -%0, %1, %1\n v_fma_f32 %1, -%1, %2, %2\n v_fma_f32 %2, -%2, %3, %3\n v_fma_f32 %3, -%3, %0, %0") \
+	X(60, "v_cmp_class_f32", "v_cmp_class_f32 vcc, %0, %4\n v_cmp_class_f32 vcc, %1, %5\n v_cmp_class_f32 vcc, %2, %6\n v_cmp_class_f32 vcc, %3, %7") \
 	X(36, "v_add_u32(inline 4)", "v_add_u32 %4, 4, %4\n v_add_u32 %5, 4, %5\n v_add_u32 %6, 4, %6\n v_add_u32 %7, 4, %7")
 
 template <int OP>

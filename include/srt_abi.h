@@ -281,7 +281,8 @@ int srt_pipeline_flush(srt_tracer *t, uint8_t *argb_out, long long *frame_delive
  * the floats in [2^-96, inf) (all of them at stride 1; must be 0); out[13] = mismatch count of the camera
  * rays' division by the image size through the host's reciprocal against IEEE `/` (must be 0);
  * out[14] = mismatch count of the kernel's branch-free sign() against detmath's on all bit patterns (must be 0);
- * out[15] = 0 (reserved). */
+ * out[15] = mismatch count of the sun lobe's power with a wave-uniform integer exponent against detmath's dm_powi, exponents
+ * 1..32 over the RNG outputs, their negatives and all bit patterns (must be 0). */
 int srt_selftest_math(srt_tracer *t, uint32_t stride, uint64_t out[16]);
 
 /* Library / build identification, e.g. "srt-hip gfx950 parity fp-contract=off". */

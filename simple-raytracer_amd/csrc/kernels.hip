@@ -864,6 +864,31 @@ __device__ __forceinline__ const SRT_AS_CONST TraceParams *cold_params() {
 #define SRT_COLD(p) (p)
 #endif
 
+// dm_powi (detmath.h) for a WAVE-UNIFORM exponent 1 <= n <= 32: the same squarings and products in double, in the same
+// order, but the exponent's bits steer scalar branches. Written as in detmath.h the compiler turns the loop's `first ? b :
+// r * b` and the conditional squaring into selects on 64-bit values: ~45 v_cndmask per call, in runs (which stall on gfx950),
+// for what is four squarings and two products when n = 25.
+__device__ __forceinline__ float powi_uniform(float x, int n) {
+#ifndef SRT_NO_POWI_UNIFORM
+	uint32_t un = (uint32_t)__builtin_amdgcn_readfirstlane(n);
+	double b = (double)x;
+	while (!(un & 1u)) { // (n >= 1: there is a set bit) squarings below the lowest set bit
+		b = b * b;
+		un >>= 1;
+	}
+	double r = b; // detmath's `first` product
+	un >>= 1;
+	while (un) {
+		b = b * b;
+		if (un & 1u) r = r * b;
+		un >>= 1;
+	}
+	return (float)r;
+#else
+	return dm_powi(x, n);
+#endif
+}
+
 // render.cl:380-394
 __device__ __forceinline__ f3 sky_box(const TraceParams &p_live, f3 dir) {
 	const auto &p = SRT_COLD(p_live);
@@ -872,7 +897,7 @@ __device__ __forceinline__ f3 sky_box(const TraceParams &p_live, f3 dir) {
 	const float lobe_x = dm_max(dot3(dir, neg(sun_dir)), 0.0f);
 	float lobe;
 	if (p.sun_focus_int > 0) {
-		lobe = dm_powi(lobe_x, p.sun_focus_int); // dm_powf's x == 1 and NaN cases fall out of the products
+		lobe = powi_uniform(lobe_x, p.sun_focus_int); // dm_powf's x == 1 and NaN cases fall out of the products
 	} else {
 		lobe = dm_powf(lobe_x, p.sd.sun_focus);
 	}
@@ -2161,6 +2186,7 @@ __global__ __launch_bounds__(256) void srt_resolve_kernel(const ResolveParams p)
 //   out[12] sqrt_rsq(bits r) != __builtin_sqrtf for r a float in [2^-96, +inf) (every one of them at stride 1)
 //   out[13] div_by_rcp((px + u), W, 1 / W) != (px + u) / W over eight image sizes W (the host's 1 / W passed in)
 //   out[14] sign_fast(bits r) != dm_sign
+//   out[15] powi_uniform(x, n) != dm_powi(x, n) for x = u, -u and the float with r's bits, n = 1 + (block % 32)
 // ---------------------------------------------------------------------------------
 namespace {
 __device__ __forceinline__ bool same_float(float a, float b) { return (a != a && b != b) || dm_f2u(a) == dm_f2u(b); }
@@ -2183,7 +2209,8 @@ struct SelftestSizes {
 };
 __global__ __launch_bounds__(256) void srt_selftest_kernel(unsigned long long *out, uint32_t stride, const SelftestSizes sz) {
 	unsigned long long bad_sqrt = 0, bad_log = 0, bad_cos = 0, s_log = 0, s_cos = 0, s_sqrt = 0, s_atan = 0, s_pow = 0;
-	unsigned long long bad_div = 0, bad_norm = 0, bad_rn = 0, bad_fold = 0, bad_rsq = 0, bad_cam = 0, bad_sign = 0;
+	unsigned long long bad_div = 0, bad_norm = 0, bad_rn = 0, bad_fold = 0, bad_rsq = 0, bad_cam = 0, bad_sign = 0, bad_powi = 0;
+	const int pw_n = 1 + (int)(blockIdx.x & 31u); // (uniform per workgroup, as powi_uniform requires)
 	const unsigned long long total = (0x100000000ull + stride - 1) / stride;
 	for (unsigned long long i = blockIdx.x * (unsigned long long)blockDim.x + threadIdx.x; i < total;
 	     i += (unsigned long long)gridDim.x * blockDim.x) {
@@ -2214,6 +2241,10 @@ __global__ __launch_bounds__(256) void srt_selftest_kernel(unsigned long long *o
 		bad_rn += same_float(sqrt_core(arg), __builtin_sqrtf(arg)) ? 0 : 1;
 #endif
 		bad_sign += same_float(sign_fast(asbits), dm_sign(asbits)) ? 0 : 1;
+		bad_powi += (same_float(powi_uniform(u, pw_n), dm_powi(u, pw_n)) && same_float(powi_uniform(-u, pw_n), dm_powi(-u, pw_n)) &&
+		             same_float(powi_uniform(asbits, pw_n), dm_powi(asbits, pw_n)))
+		                ? 0
+		                : 1;
 		if (r >= 0x0f800000u && r < 0x7f800000u) bad_rsq += same_float(sqrt_rsq(asbits), __builtin_sqrtf(asbits)) ? 0 : 1;
 		{
 			const float W = sz.w[r & 7u];
@@ -2247,6 +2278,7 @@ __global__ __launch_bounds__(256) void srt_selftest_kernel(unsigned long long *o
 	atomicAdd(&out[12], bad_rsq);
 	atomicAdd(&out[13], bad_cam);
 	atomicAdd(&out[14], bad_sign);
+	atomicAdd(&out[15], bad_powi);
 }
 
 void srt_launch_selftest(unsigned long long *out, uint32_t stride, void *stream) {

@@ -231,6 +231,7 @@ def test_device_math_equals_host_math(T, oracle):
     assert full[11] == 0, f"folding the 2^-32 RNG scaling changes log or theta on {full[11]} RNG outputs"
     assert full[12] == 0, f"sqrt_rsq differs from IEEE sqrt on {full[12]} floats of [2^-96, inf)"
     assert full[14] == 0, f"sign_fast differs from dm_sign on {full[14]} bit patterns"
+    assert full[15] == 0, f"powi_uniform differs from dm_powi on {full[15]} (value, exponent) pairs"
     assert full[13] == 0, f"division by the image size through the host's reciprocal differs from IEEE division on {full[13]} of 2^32 quotients"
     dev = t.selftest_math(61)
     host = oracle.math_checksums(61)

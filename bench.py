@@ -227,8 +227,9 @@ def measure_config(name, sky, accel, steps, warmup, device):
         t.synchronize()
         walls.append(time.perf_counter() - t0)
         kms.append(t.last_trace_kernel_ms())
-    # the MEDIAN step: this runs in the process that has just released the headline's 25 GB, and one step of a 0.2 ms config
-    # that catches the driver at it (seen: 75 ms) would otherwise be the whole average
+    # the MEDIAN step (wall and kernel time alike): this runs in the process that has just released the headline's 25 GB, and
+    # one step of a 0.2 ms config that catches the device at it (seen: 75-80 ms between the launch's two events) would
+    # otherwise be the whole average
     dt = float(np.median(walls))
     c = t.counters()
     launches, overlapped = t.last_trace_launches()
@@ -241,9 +242,9 @@ def measure_config(name, sky, accel, steps, warmup, device):
             ci = t.counters()
             per["tri_tests"], per["tri_pass_u"] = ci["tri_tests"], ci["tri_pass_u"]
             t.count_triangles(False)
-        frac = round(w_ops(per, shapes) / (float(np.mean(kms)) * 1e-3) / VALU_PEAK_LANE_OPS, 4)
+        frac = round(w_ops(per, shapes) / (float(np.median(kms)) * 1e-3) / VALU_PEAK_LANE_OPS, 4)
     out = {"workload": desc + (" [BVH, srt_set_acceleration]" if accel == "bvh" else ""), "steps": steps, "ms_per_step": round(dt * 1e3, 3), "ms_per_step_is": "median of the steps' wall times", "ms_per_step_max": round(max(walls) * 1e3, 3),
-           "kernel_ms": round(float(np.mean(kms)), 3), "kernel_ms_is": "span of overlapping sample-batch launches" if overlapped else "sum of the launches' own durations",
+           "kernel_ms": round(float(np.median(kms)), 3), "kernel_ms_max": round(float(max(kms)), 3), "kernel_ms_is": ("span of overlapping sample-batch launches" if overlapped else "sum of the launches' own durations") + " (median step)",
            "launches_per_step": launches, "mray_s": round(per["rays"] / dt / 1e6, 1), "rays_per_step": per["rays"], "frac": frac}
     if accel == "bvh":
         out["frac_note"] = "W_ops (SURVEY 8d) has no term for hierarchy steps: no roofline fraction for the BVH walk"

@@ -935,7 +935,7 @@ __device__ __forceinline__ f3 sky_box(const TraceParams &p_live, f3 dir) {
 #define SRT_SUB_MODELS 64
 #endif
 #ifndef SRT_SUB_BVH
-#define SRT_SUB_BVH 128
+#define SRT_SUB_BVH 64 // (round 2 measured 128 faster -- with chunks of 5 sub-jobs: it was the chunk, not the sub-job; srt_abi.hip)
 #endif
 // SHADE runs when hits + queued paths reach this many lanes (64 = always a full wave)
 #ifndef SRT_SHADE_MIN

@@ -1092,7 +1092,7 @@ int srt_trace(srt_tracer *t, const srt_render_data *options) {
 		// Scenes with models: what a chunk costs varies wildly with where it lies (pixels on a glass mesh: ten walks or scans
 		// per path; sky pixels: none), and the launch ends when the wave with the last expensive chunk does. Small chunks
 		// shorten that tail, but a wave that hops between distant pixels loses the coherence of neighbouring rays (BVH blocks,
-		// scans shared by a wave-full): about 2.5 pixels' worth of samples per chunk, between 2 and 8 sub-jobs. Measured, chunks
+		// scans shared by a wave-full): about 2.5 pixels' worth of samples per chunk, between 2 and 8 sub-jobs (BVH: 16). Measured, chunks
 		// of 1 / 2 / 5 sub-jobs: BVH walk of the 10^5-triangle mesh at 16 spp 5.1 / 5.0 / 7.2 ms, at 256 spp 63.9 / 46.8 / 39.0;
 		// array scan of the two 968-triangle meshes at 32 spp 20.2 / 16.0 / 18.1. At full size (round 3, profiles/README.md),
 		// chunks of 4 / 5 / 6 / 8 / 12 / 16 sub-jobs: configs[2] array scan (512 spp, sub-jobs of 64) 134.7 / 128.0 / 124.1 / 121.7 /
@@ -1102,7 +1102,10 @@ int srt_trace(srt_tracer *t, const srt_render_data *options) {
 		unsigned long long cap_subs = 5ull;
 		if (t->num_models > 0) {
 			cap_subs = (5ull * nbs / 2ull + sub - 1ull) / sub;
-			cap_subs = cap_subs < 2ull ? 2ull : (cap_subs > 8ull ? 8ull : cap_subs);
+			// (BVH, sub-jobs of 64: chunks of 10 / 16 sub-jobs configs[2] 39.3 / 35.7 ms, configs[4] 35.7-36.5 / 36.5 ms; sub-jobs of 128
+			// and 8: 37.0 / 36.3)
+			const unsigned long long most = t->bvh_active ? 16ull : 8ull;
+			cap_subs = cap_subs < 2ull ? 2ull : (cap_subs > most ? most : cap_subs);
 		}
 		if (const char *env = getenv("SRT_JOB_CAP_SUBS")) // experiments only
 			if (atoi(env) > 0) cap_subs = (unsigned long long)atoi(env);

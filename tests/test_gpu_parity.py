@@ -107,6 +107,32 @@ def test_scan_pool_sizes_are_invisible(T, sky, oracle, monkeypatch):
             monkeypatch.delenv(env)
 
 
+@pytest.mark.parametrize("accel", [0, 1])
+def test_chunk_sizes_are_invisible(T, sky, oracle, monkeypatch, accel):
+    """How many sub-jobs the work cursor hands out at a time (srt_trace's rule, or SRT_JOB_CAP_SUBS) decides which wave traces
+    which path and nothing else: array scan and BVH, chunks of 1 / 3 / 16 sub-jobs and the rule's own choice give the oracle's canvas."""
+    shapes, tris, mats = S.mesh_scene(2)
+    rd = R.render_data(96, 54, 40, 10, camera_to_world=S.default_camera(), time=31337)
+    g = dict(shapes=shapes, tris=tris, mats=mats, rd=rd, sd=R.scene_data(len(shapes)))
+    want = oracle.render(rd, g["sd"], shapes, tris, mats, sky)
+    for cap in (None, "1", "3", "16"):
+        if cap:
+            monkeypatch.setenv("SRT_JOB_CAP_SUBS", cap)
+        t = T.Tracer(96, 54)
+        t.set_skybox(sky)
+        if accel:
+            t.set_acceleration(T.ACCEL_BVH)
+        t.options, t.scene_data = rd.copy(), g["sd"].copy()
+        t.update_scene(shapes, tris, mats)
+        t.clear_canvas()
+        t.trace()
+        assert bits_equal(t.read_canvas(), want), f"accel {accel}, chunks of {cap} sub-jobs"
+        assert t.counters()["watchdog"] == 0
+        t.close()
+        if cap:
+            monkeypatch.delenv("SRT_JOB_CAP_SUBS")
+
+
 def test_100k_triangle_mesh_vs_oracle(T, sky, oracle):
     """configs[4] geometry (one 99,904-triangle flat mesh + plane), tiny canvas so the
     brute-force oracle finishes in seconds."""

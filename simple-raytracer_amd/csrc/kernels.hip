@@ -629,8 +629,10 @@ __device__ __forceinline__ bool test_aabb(float lx, float ly, float lz, float hx
 //   R3  sh*a < 0 and |sh| >= 0.001 |a| =>  u < 0, not an underflow to -0
 // Each implies the reference's miss for every finite, infinite or denormal a (margins of
 // 2^-10 dwarf the 2^-22 worst-case relative error of fl(1/a)*sh; NaNs compare false and
-// fall through). Lanes not rejected run the reference's exact sequence; the wave skips
-// it when no lane is left (s_cbranch_execz). Results are therefore bit-identical.
+// fall through). Lanes not rejected compute the reference's q and dot(dir, q) and meet two
+// more such rejects, on v (R4, R5 below); what is left runs the reference's exact sequence.
+// The wave skips each stage when no lane is left (s_cbranch_execz). Results are therefore
+// bit-identical.
 // Returns true when the reference accepts the triangle; t is then its hit distance.
 template <bool COUNT_TRIS>
 __device__ __forceinline__ bool moller_trumbore(float v0x, float v0y, float v0z, float e1x, float e1y, float e1z, float e2x, float e2y,
@@ -645,15 +647,31 @@ __device__ __forceinline__ bool moller_trumbore(float v0x, float v0y, float v0z,
 	bool ok = false;
 	if (!reject) {
 		SRT_REGION(EXTEND_TRI_EXACT);
-		float f = 1.0f / a;
-		float u = f * sh;
-		ok = !(u < 0.0f || u > 1.0f);
-		if (COUNT_TRIS) n_tri_u += (ok && counted) ? 1u : 0u; // padding triangles (NaN rays reach here) are not tests
+		// The reference's q and dot(dir, q) first, and two more division-free rejects on v = f * dv before the IEEE reciprocal
+		// (11 instructions that a wave pays as soon as ONE lane is left):
+		//   R4  dv*a < 0 and |dv| >= 0.001 |a|  =>  v < 0, not an underflow to -0        (as R3 for u)
+		//   R5  |sh + dv| > 1.01 |a|             =>  |u + v| > 1: u + v > 1, or one of u, v is below -0.5
+		// (u + v as the reference rounds it differs from (sh + dv) / a by parts in 10^6; NaNs compare false and fall through).
+		// Meshes whose triangles are large on screen send a third of all wave-tests past R1-R3 with a handful of lanes each;
+		// most of those lanes fail on v. The instrumented variant counts the lanes that pass the u test and keeps them all.
+		// (Measured and left out: the same for t -- dt*a < 0 => t not > 0, |dt| > 1.001 tmin |a| => not closer -- costs the
+		// wave-tests that get here more than the reciprocals it saves: configs[2] 107.2 -> 108.6 ms, configs[4] 4,297 -> 4,340.)
 		f3 q = cross3(sv, e1);
-		float v = f * dot3(dir, q);
-		ok = ok && !(v < 0.0f || u + v > 1.0f);
-		t = f * dot3(e2, q);
-		ok = ok && t > 0.0f;
+		float dv = dot3(dir, q);
+		bool reject2 = false;
+#ifndef SRT_NO_TRI_V_REJECT
+		if (!COUNT_TRIS) reject2 = ((dv * a < 0.0f) && (dm_fabs(dv) >= aa * 0.001f)) || (dm_fabs(sh + dv) > aa * 1.01f);
+#endif
+		if (!reject2) {
+			float f = 1.0f / a;
+			float u = f * sh;
+			ok = !(u < 0.0f || u > 1.0f);
+			if (COUNT_TRIS) n_tri_u += (ok && counted) ? 1u : 0u; // padding triangles (NaN rays reach here) are not tests
+			float v = f * dv;
+			ok = ok && !(v < 0.0f || u + v > 1.0f);
+			t = f * dot3(e2, q);
+			ok = ok && t > 0.0f;
+		}
 	}
 	return ok;
 }

@@ -28,7 +28,7 @@ PHASE_OF = {  # region -> phase of DESIGN.md's split
     "PROLOGUE": "other", "EPILOGUE": "other", "LOOP_HEAD": "loop", "LOOP_TAIL": "loop",
     "EXTEND_SETUP": "extend", "EXTEND_GROUP": "extend",
     **{f"EXTEND_{n}_{k}": "extend" for n in ("SPHERES2", "SPHERES4", "PLANES", "MODEL") for k in range(3)},
-    "EXTEND_SUSPEND": "extend", "EXTEND_TRI_LOOP": "extend", "EXTEND_TRI_EXACT": "extend", "EXTEND_BVH_STEP": "extend", "EXTEND_FINISH": "extend",
+    "EXTEND_SUSPEND": "extend", "EXTEND_TRI_LOOP": "extend", "EXTEND_TRI_EXACT": "extend", "EXTEND_TRI_DIV": "extend", "EXTEND_BVH_STEP": "extend", "EXTEND_FINISH": "extend",
     "SKY_PUSH": "sky", "SKY_RESOLVE": "sky",
     "SHADE_HEAD": "shade", "SHADE_POP": "shade", "SHADE_WINNER": "shade", "SHADE_MESH_NORMAL": "shade", "SHADE_MATERIAL": "shade",
     "SHADE_BOUNCE": "shade", "SHADE_OPAQUE": "shade", "SHADE_GLASS": "shade", "SHADE_REFRACT": "shade", "SHADE_TAIL": "shade", "PARK": "shade",

@@ -46,7 +46,7 @@
 	X(PROLOGUE) X(LOOP_HEAD) X(EXTEND_SETUP) X(EXTEND_GROUP) X(EXTEND_SUSPEND)                                                       \
 	X(EXTEND_SPHERES2_0) X(EXTEND_SPHERES2_1) X(EXTEND_SPHERES2_2) X(EXTEND_SPHERES4_0) X(EXTEND_SPHERES4_1) X(EXTEND_SPHERES4_2)   \
 	X(EXTEND_PLANES_0) X(EXTEND_PLANES_1) X(EXTEND_PLANES_2) X(EXTEND_MODEL_0) X(EXTEND_MODEL_1) X(EXTEND_MODEL_2)                   \
-	X(EXTEND_TRI_LOOP) X(EXTEND_TRI_EXACT) X(EXTEND_BVH_STEP) X(EXTEND_FINISH) X(SKY_PUSH) X(SKY_RESOLVE) X(SHADE_HEAD) X(SHADE_POP) X(SHADE_WINNER)   \
+	X(EXTEND_TRI_LOOP) X(EXTEND_TRI_EXACT) X(EXTEND_TRI_DIV) X(EXTEND_BVH_STEP) X(EXTEND_FINISH) X(SKY_PUSH) X(SKY_RESOLVE) X(SHADE_HEAD) X(SHADE_POP) X(SHADE_WINNER)   \
 	X(SHADE_MESH_NORMAL) X(SHADE_MATERIAL) X(SHADE_BOUNCE) X(SHADE_OPAQUE) X(SHADE_GLASS) X(SHADE_REFRACT) X(SHADE_TAIL) X(PARK)     \
 	X(HANDIN) X(HANDIN_ORPHAN) X(REFILL_HEAD) X(REFILL_SCANQ) X(REFILL_POOL) X(REFILL_UNPARK) X(REFILL_LOOP) X(REFILL_OPEN) X(REFILL_FLUSH) X(REFILL_CURSOR)         \
 	X(REFILL_TAKE) X(CAMERA) X(LOOP_TAIL) X(EPILOGUE)
@@ -663,6 +663,7 @@ __device__ __forceinline__ bool moller_trumbore(float v0x, float v0y, float v0z,
 		if (!COUNT_TRIS) reject2 = ((dv * a < 0.0f) && (dm_fabs(dv) >= aa * 0.001f)) || (dm_fabs(sh + dv) > aa * 1.01f);
 #endif
 		if (!reject2) {
+			SRT_REGION(EXTEND_TRI_DIV);
 			float f = 1.0f / a;
 			float u = f * sh;
 			ok = !(u < 0.0f || u > 1.0f);

@@ -505,7 +505,7 @@ def main():
                         "note": "design bytes = algorithmic bytes (SURVEY.md 8d W_bytes) + 24 B per path of radiance written by the trace kernel and read by the ordered reduction"},
             },
         }
-        if world > 1:
+        if collect:  # (also the one-rank rehearsal of the N > 1 path, SRT_BENCH_COLLECT=1)
             line["per_rank"] = {"trace_kernel_ms_min": round(trace_ms_min, 3), "trace_kernel_ms_max": round(trace_ms_max, 3),
                                 "gather_ms": round(gather_ms_max, 3),
                                 "gather_ms_is": "max over ranks of: collective + unpermute + (rank 0) resolve of the gathered frame, on the launch stream, behind the rank's trace"}

@@ -98,6 +98,37 @@ def valu_cost(mn):
     return 1.75
 
 
+# Round 4: what an instruction of each kind costs the LAUNCH, measured in place -- the sphere kernel at full size with 100 extra
+# instructions of one kind per loop iteration (scripts/r04_issue_cost.sh, profiles/r04_issue_cost.json), in units of one
+# v_add_f32. Scalar instructions are not free (the kernel's time follows the waves' whole instruction stream, not the VALU
+# count alone); kinds not measured carry the figure of the nearest measured one.
+def issue_cost(mn, cls):
+    base = re.sub(r"_(e32|e64|sdwa|dpp)$", "", mn)
+    if cls == "s_nop":
+        return 0.24
+    if cls == "salu":
+        return 1.03 if base.startswith(("s_mov", "s_movk")) else 1.32
+    if cls == "branch":
+        return 0.75  # s_cmp + branch: 1.4 not taken, 2.4 taken (to the next instruction); the compare is counted as salu
+    if cls == "wait":
+        return 0.24  # as s_nop; what it waits for is not modelled
+    if cls in ("smem", "lds", "vmem"):
+        return 1.3  # not measured: taken as a scalar instruction
+    if cls == "lane":
+        return 2.55
+    if cls in ("trans", "fp64"):
+        return 5.2
+    if base.startswith(("v_mul_lo", "v_mul_hi", "v_mad_u32", "v_mad_i32")):
+        return 1.78
+    if base.startswith(("v_mad_u64", "v_mad_i64")):
+        return 5.2
+    if base in ("v_add_f32", "v_sub_f32", "v_subrev_f32", "v_mul_f32", "v_fma_f32", "v_fmac_f32", "v_fmaak_f32", "v_fmamk_f32", "v_mac_f32", "v_mov_b32"):
+        return 1.0 if base != "v_fma_f32" else 1.08
+    if base in ("v_xor_b32", "v_and_b32", "v_or_b32", "v_not_b32", "v_lshrrev_b32", "v_ashrrev_i32", "v_add_u32", "v_sub_u32", "v_subrev_u32"):
+        return 1.31
+    return 1.65  # compares, selects, conversions, min / max / med3, left shifts, bit-field and three-operand integer ops
+
+
 LLVM_BIN = Path("/opt/rocm/lib/llvm/bin")
 
 
@@ -311,6 +342,7 @@ def static_mix(kernel, flags, cache="/tmp/srt_phase_mix.hsaco"):
             per_region[r][classify(mn)] += 1
             if classify(mn) in VALU_CLASSES:
                 per_region[r]["valu_cost"] += valu_cost(mn)
+            per_region[r]["issue_cost"] += issue_cost(mn, classify(mn))
             listing.append((addr, r, classify(mn), text, " < ".join(f"{fn.split('(')[0]}:{line}" for fn, _, line in stacks[i]), k))
     static_mix.listing = listing
     return {r: dict(c) for r, c in per_region.items()}
@@ -356,7 +388,7 @@ def main():
     for r, c in st.items():
         f = waves.get(r, alias.get(r, 0))
         n = static_mix.copies.get(r, 1)
-        ex = {k: c.get(k, 0) * f / n for k in CLASSES + ["valu_cost"]}
+        ex = {k: c.get(k, 0) * f / n for k in CLASSES + ["valu_cost", "issue_cost"]}
         out_regions[r] = {"phase": PHASE_OF.get(r, "other"), "wave_executions": f, "inlined_copies": n, "lanes_per_execution": round(lanes.get(r, 0) / f, 2) if f else None,
                           "static": {k: c.get(k, 0) for k in CLASSES if c.get(k, 0)}, "executed": {k: v for k, v in ex.items() if v}}
         phases[PHASE_OF.get(r, "other")].update(ex)
@@ -373,6 +405,9 @@ def main():
         "per_phase_valu": {p: int(sum(c[k] for k in VALU_CLASSES)) for p, c in phases.items()},
         "per_phase_valu_cost_share": {p: round(c["valu_cost"] / max(sum(cc["valu_cost"] for cc in phases.values()), 1), 4) for p, c in phases.items()},
         "valu_cost_note": "valu_cost = executed VALU instructions weighted by their measured issue cost (full-rate fp32 / logic / shift-right / integer add = 1, half-rate classes 1.75, transcendental 3.43; isa_phase_mix.py valu_cost)",
+        "per_phase_issue_cost_share": {p: round(c["issue_cost"] / max(sum(cc["issue_cost"] for cc in phases.values()), 1), 4) for p, c in phases.items()},
+        "issue_cost_note": "issue_cost = every executed instruction (vector AND scalar) weighted by what one more of its kind costs the launch, in v_add_f32 units (isa_phase_mix.py issue_cost, profiles/r04_issue_cost.json)",
+        "issue_cost_per_wave_ray": round(64 * sum(c["issue_cost"] for c in phases.values()) / rays, 1),
         "per_phase_valu_share": {p: round(sum(c[k] for k in VALU_CLASSES) / valu_total, 4) for p, c in phases.items()},
         "per_phase_valu_lane_slots_per_ray": {p: round(64 * sum(c[k] for k in VALU_CLASSES) / rays, 1) for p, c in phases.items()},
         "total_executed": {k: int(v) for k, v in total.items() if v},
@@ -397,7 +432,7 @@ def main():
     txt = json.dumps(res, indent=1)
     if a.out:
         Path(a.out).write_text(txt + "\n")
-    print(json.dumps({k: res[k] for k in ("per_phase_valu_cost_share", "per_phase_valu_share", "per_phase_valu_lane_slots_per_ray", "valu_class_share", "valu_lane_slots_per_ray", "pmc_check") if k in res}, indent=1))
+    print(json.dumps({k: res[k] for k in ("per_phase_issue_cost_share", "issue_cost_per_wave_ray", "per_phase_valu_cost_share", "per_phase_valu_share", "per_phase_valu_lane_slots_per_ray", "valu_class_share", "valu_lane_slots_per_ray", "pmc_check") if k in res}, indent=1))
 
 
 if __name__ == "__main__":

@@ -1012,6 +1012,13 @@ __device__ __forceinline__ f3 sky_box(const TraceParams &p_live, f3 dir) {
 #ifndef SRT_WT_ALL
 #define SRT_WT_ALL 1
 #endif
+// 1: no LDS staging of radiances at all -- every path stores its 12 bytes itself when it ends (SRT_DIRECT_STORE: 0 plain, 1 sc1, 2 nt)
+#ifndef SRT_DIRECT_RADIANCE
+#define SRT_DIRECT_RADIANCE 0
+#endif
+#ifndef SRT_DIRECT_STORE
+#define SRT_DIRECT_STORE 0
+#endif
 namespace {
 // One wave writes a sub-job's radiances (n items, packed 12-byte items in LDS) to HBM: whole
 // 64-byte lines, 16 B per lane per store. Both sides are 16-byte aligned (sub-jobs start on
@@ -1026,6 +1033,7 @@ namespace {
 // they were acknowledged (s_waitcnt vmcnt(0)), and the kernel publishes a ray only behind that wait.
 template <bool WT = false>
 __device__ __forceinline__ void flush_stage(const float *__restrict__ src, float *__restrict__ dst, uint32_t n_items, int lane) {
+	if (SRT_DIRECT_RADIANCE) return;
 	asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 	const uint32_t n = n_items * 3u, n4 = n >> 2;
 	const float4 *__restrict__ s4 = reinterpret_cast<const float4 *>(src);
@@ -1058,6 +1066,16 @@ struct Stage {
 // else (its buffer was needed and written out meanwhile) straight to HBM. f0 / f1 report which.
 template <uint32_t SUB, bool WT = false>
 __device__ __forceinline__ void deliver(const Stage &st, float *__restrict__ stage, float *__restrict__ radiance, uint32_t item, f3 c, bool &f0, bool &f1 SRT_RC_PARAM) {
+	if (SRT_DIRECT_RADIANCE) {
+		typedef float f3v __attribute__((ext_vector_type(3)));
+		f3v v;
+		v.x = c.x, v.y = c.y, v.z = c.z;
+		float *g = radiance + 3ull * item;
+		if (SRT_DIRECT_STORE == 1) asm volatile("global_store_dwordx3 %0, %1, off sc1" : : "v"(g), "v"(v) : "memory");
+		else if (SRT_DIRECT_STORE == 2) asm volatile("global_store_dwordx3 %0, %1, off nt" : : "v"(g), "v"(v) : "memory");
+		else asm volatile("global_store_dwordx3 %0, %1, off" : : "v"(g), "v"(v) : "memory");
+		return;
+	}
 	const uint32_t d0 = item - st.base0, d1 = item - st.base1;
 	if (d0 < st.total0) {
 		float *s = stage + 3u * d0;
@@ -1188,7 +1206,7 @@ __global__ __launch_bounds__(64, USE_BVH ? SRT_TRACE_WAVES_PER_SIMD_BVH : HAS_MO
 	uint32_t qpix0 = 0, qpix1 = 0, koff0 = 0, koff1 = 0; // pixel and sample offset of each staged sub-job's first item
 	uint32_t issued = 0, cur = 0;                        // items of buffer `cur` handed out so far
 	float *__restrict__ stage = reinterpret_cast<float *>(lds + p.stage_off); // [2][SUB] packed {r, g, b}
-	float *__restrict__ ring = stage + 2u * SUB * 3u;                          // [10][64] escaped paths awaiting their sky lookup
+	float *__restrict__ ring = stage + (SRT_DIRECT_RADIANCE ? 0u : 2u * SUB * 3u);                          // [10][64] escaped paths awaiting their sky lookup
 	float *__restrict__ hq = ring + 10u * (uint32_t)SRT_RING_CAP;                                 // [16..18][HQ] paths that hit, awaiting their bounce (FIFO)
 	constexpr uint32_t HQ = USE_BVH ? SRT_HQ_CAP_BVH : SRT_HQ_CAP;
 #ifdef SRT_REGION_COUNT
@@ -1257,6 +1275,61 @@ __global__ __launch_bounds__(64, USE_BVH ? SRT_TRACE_WAVES_PER_SIMD_BVH : HAS_MO
 		bool suspended0 = false, suspended1 = false; // SUSPEND: the lane's ray went to scan stack 0 / 1 in this iteration
 		if (SRT_DIAG_ON) w_iter++;
 		SRT_CLK(6);
+#ifdef SRT_DUMMY_KIND
+		// (regime probe, development builds only; scripts/r04_issue_cost.sh) 100 extra instructions of one kind per loop iteration
+		// that compute nothing: what an instruction of each kind costs the launch tells what the kernel's time is made of
+		{
+			float d0 = org.x, d1 = org.y, d2 = org.z, d3 = dir.x;
+			uint32_t s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+#define SRT_DUMMY4(I) asm volatile(".rept 25\n " I(0, 4) "\n " I(1, 5) "\n " I(2, 6) "\n " I(3, 7) "\n .endr" : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3), "+s"(s0), "+s"(s1), "+s"(s2), "+s"(s3) : "v"(dir.y), "v"(dir.z) : "scc", "vcc")
+#if SRT_DUMMY_KIND == 1
+#define SRT_DI(k, q) "v_add_f32 %" #k ", 1.0, %" #k
+#elif SRT_DUMMY_KIND == 2
+#define SRT_DI(k, q) "v_max_f32 %" #k ", 1.0, %" #k
+#elif SRT_DUMMY_KIND == 3
+#define SRT_DI(k, q) "s_add_u32 %" #q ", %" #q ", 1"
+#elif SRT_DUMMY_KIND == 4
+#define SRT_DI(k, q) "v_fma_f32 %" #k ", %8, %9, %" #k
+#elif SRT_DUMMY_KIND == 5
+#define SRT_DI(k, q) "v_mul_lo_u32 %" #k ", %" #k ", %8"
+#elif SRT_DUMMY_KIND == 6
+#define SRT_DI(k, q) "v_cndmask_b32 %" #k ", %" #k ", %8, vcc"
+#elif SRT_DUMMY_KIND == 7
+#define SRT_DI(k, q) "v_cmp_lt_f32 vcc, %" #k ", %8"
+#elif SRT_DUMMY_KIND == 8
+#define SRT_DI(k, q) "v_rcp_f32 %" #k ", %" #k
+#elif SRT_DUMMY_KIND == 9
+#define SRT_DI(k, q) "v_mov_b32 %" #k ", %8"
+#elif SRT_DUMMY_KIND == 10
+#define SRT_DI(k, q) "s_mov_b32 %" #q ", 0x12345678"
+#elif SRT_DUMMY_KIND == 11
+#define SRT_DI(k, q) "s_nop 0"
+#elif SRT_DUMMY_KIND == 12
+#define SRT_DI(k, q) "v_add_f32 %" #k ", 0x40490fdb, %" #k
+#elif SRT_DUMMY_KIND == 13
+#define SRT_DI(k, q) "v_xor_b32 %" #k ", %8, %" #k
+#elif SRT_DUMMY_KIND == 14
+#define SRT_DI(k, q) "v_add_u32 %" #k ", %8, %" #k
+#elif SRT_DUMMY_KIND == 15
+#define SRT_DI(k, q) "v_cvt_f32_u32 %" #k ", %" #k
+#elif SRT_DUMMY_KIND == 16
+#define SRT_DI(k, q) "s_and_b64 vcc, vcc, exec"
+#elif SRT_DUMMY_KIND == 17
+#define SRT_DI(k, q) "v_readfirstlane_b32 %" #q ", %" #k
+#elif SRT_DUMMY_KIND == 18
+#define SRT_DI(k, q) "s_cmp_eq_u32 %" #q ", 77\n s_cbranch_scc1 1f\n 1:" // compare + branch not taken
+#elif SRT_DUMMY_KIND == 21
+#define SRT_DI(k, q) "s_cmp_lg_u32 %" #q ", 77\n s_cbranch_scc1 1f\n 1:" // compare + branch taken (to the next instruction)
+#elif SRT_DUMMY_KIND == 22
+#define SRT_DI(k, q) "v_sub_f32 %" #k ", %" #k ", %8\n v_mul_f32 %" #k ", %" #k ", %9" // two dependent full-rate instructions
+#elif SRT_DUMMY_KIND == 19
+#define SRT_DI(k, q) "v_mul_f32 %" #k ", %8, %" #k
+#elif SRT_DUMMY_KIND == 20
+#define SRT_DI(k, q) "v_lshlrev_b32 %" #k ", 1, %" #k
+#endif
+			SRT_DUMMY4(SRT_DI);
+		}
+#endif
 		// ================= EXTEND: closest_intersection (render.cl:293-378), winner deferred =================
 		if (n_active != 0u) { // lanes that hold a ray (counted at the end of the previous iteration: no vote here)
 			if (nb > 0) {
@@ -2321,7 +2394,7 @@ int srt_sub_job_items(int has_models, int use_bvh) { return !has_models ? SRT_SU
 int srt_trace_lds_floats(int has_models, int use_bvh) {
 	// two staging buffers of packed 12-byte items, the sky ring (10 fields), the hit queue (16..18 fields)
 	const int sub = srt_sub_job_items(has_models, use_bvh);
-	int n = 2 * sub * 3 + 10 * SRT_RING_CAP + (has_models ? (use_bvh ? 18 * SRT_HQ_CAP_BVH : 17 * SRT_HQ_CAP) : 16 * SRT_HQ_CAP);
+	int n = (SRT_DIRECT_RADIANCE ? 0 : 2 * sub * 3) + 10 * SRT_RING_CAP + (has_models ? (use_bvh ? 18 * SRT_HQ_CAP_BVH : 17 * SRT_HQ_CAP) : 16 * SRT_HQ_CAP);
 #ifdef SRT_REGION_COUNT
 	n += 2 * SRT_REGION_MAX; // (waves, lanes) per region
 #endif

@@ -960,9 +960,15 @@ __device__ __forceinline__ f3 sky_box(const TraceParams &p_live, f3 dir) {
 #ifndef SRT_SHADE_MIN
 #define SRT_SHADE_MIN 64
 #endif
-// paths the hit queue holds; when hits + queued paths exceed it they are shaded even if they do not fill the wave
+// paths the hit queue holds; when hits + queued paths exceed it they are shaded even if they do not fill the wave. 64: a phase's
+// hits can always be parked, so SHADE runs with a full wave except at the end of a launch (round 4, in the LDS the radiance
+// staging buffers used to take; with 40, every phase of 41..63 ready paths was shaded as it was: 59.4 lanes per SHADE phase
+// and 59.3 rays per EXTEND phase, now 63.9 and 62.8 -- 5.5 % fewer loop iterations for the same rays)
 #ifndef SRT_HQ_CAP
-#define SRT_HQ_CAP 40
+#define SRT_HQ_CAP 64
+#endif
+#ifndef SRT_HQ_CAP_MODELS
+#define SRT_HQ_CAP_MODELS 56
 #endif
 // Array-scan kernels: a model of at least this many triangles ("big", srt_abi.hip packs it alone in its block) is not
 // scanned by the few lanes whose rays happen to enter its box in one EXTEND phase; those rays wait in one of the
@@ -975,7 +981,7 @@ __device__ __forceinline__ f3 sky_box(const TraceParams &p_live, f3 dir) {
 #define SRT_SCAN_FULL 64
 #endif
 #ifndef SRT_HQ_CAP_BVH
-#define SRT_HQ_CAP_BVH SRT_HQ_CAP
+#define SRT_HQ_CAP_BVH 56
 #endif
 // entries of the sky ring (<= 64): the ring is resolved when full, one entry per lane
 #ifndef SRT_RING_CAP
@@ -1001,115 +1007,33 @@ __device__ __forceinline__ f3 sky_box(const TraceParams &p_live, f3 dir) {
 #define SRT_CLK(i)
 #endif
 
-// Radiance stores are write-through (sc1) in every kernel: measured on the sphere frame at 64 spp (1.59 GB of radiance per
-// launch; profiles/r03_radiance_store_flavours.json), trace-kernel WRITE_SIZE / FETCH_SIZE 3.73 / 2.14 GB with plain stores
-// (a straggler's 12 bytes land in a line that has left the L2: read for ownership, written back whole), 3.04 / 0.26 GB with
-// sc1 -- the kernel time is the same. (A/B: SRT_WT_ALL=0 restores plain stores outside the array scan, which needs sc1;
-// SRT_ORPHAN_STORE picks the straggler's store alone: 0 plain, 1 sc1, 2 nt -- nt is no better than plain.)
-#ifndef SRT_ORPHAN_STORE
-#define SRT_ORPHAN_STORE 0
-#endif
-#ifndef SRT_WT_ALL
-#define SRT_WT_ALL 1
-#endif
-// 1: no LDS staging of radiances at all -- every path stores its 12 bytes itself when it ends (SRT_DIRECT_STORE: 0 plain, 1 sc1, 2 nt)
-#ifndef SRT_DIRECT_RADIANCE
-#define SRT_DIRECT_RADIANCE 0
-#endif
-#ifndef SRT_DIRECT_STORE
-#define SRT_DIRECT_STORE 0
+// Radiances leave the kernel one path at a time: a path that ends stores its 12 bytes itself (round 4). Rounds 1-3 staged the
+// 64 radiances of a sub-job in LDS and wrote whole 64-byte lines; that cost 1.5 KB of LDS per wave, a flush per sub-job, two
+// votes per hand-in, and a store of its own for the 8 % of paths that outlived their buffer anyway. Without it the hit queue
+// holds 64 paths in the same LDS (every SHADE phase runs with a full wave), and the kernel is faster at the same bytes:
+// configs[1] 122.5 -> 114.4 ms (profiles/README.md, round 4). The stores are write-through (sc1): nothing stays dirty in an
+// L2, so a line whose other items arrive later is not read back for ownership (plain / sc1 / nt at full size with the queue
+// of 64: 116.7 / 114.4 / - ms; with the queue of 40: 122.6 / 120.9 / 122.3). Each item is stored exactly once, by whichever wave ends
+// its path (the array scan's ray pool hands paths between waves), and read by srt_reduce_kernel after the launch.
+#ifndef SRT_RADIANCE_STORE
+#define SRT_RADIANCE_STORE 1 // 0 plain, 1 sc1, 2 nt
 #endif
 namespace {
-// One wave writes a sub-job's radiances (n items, packed 12-byte items in LDS) to HBM: whole
-// 64-byte lines, 16 B per lane per store. Both sides are 16-byte aligned (sub-jobs start on
-// multiples of 4 items).
-//
-// One-wave workgroup: the LDS executes this wave's ds_write / ds_read in program order, so no
-// s_barrier is needed; only keep the compiler from reordering across these points.
-//
-// WT (array-scan kernels): write-through stores (sc1), which leave no dirty line behind in this XCD's L2. There a path may be
-// ended by a wave on ANOTHER XCD (the launch-end ray pool), whose store of the radiance must not be overwritten later by
-// this L2's write-back of the stale value staged here; with sc1 the order of the two stores in memory is the order in which
-// they were acknowledged (s_waitcnt vmcnt(0)), and the kernel publishes a ray only behind that wait.
-template <bool WT = false>
-__device__ __forceinline__ void flush_stage(const float *__restrict__ src, float *__restrict__ dst, uint32_t n_items, int lane) {
-	if (SRT_DIRECT_RADIANCE) return;
-	asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-	const uint32_t n = n_items * 3u, n4 = n >> 2;
-	const float4 *__restrict__ s4 = reinterpret_cast<const float4 *>(src);
-	float4 *__restrict__ d4 = reinterpret_cast<float4 *>(dst);
-	if (WT) {
-		typedef float f4v __attribute__((ext_vector_type(4)));
-		for (uint32_t i = (uint32_t)lane; i < n4; i += 64u) {
-			const float4 q = s4[i];
-			f4v v;
-			v.x = q.x, v.y = q.y, v.z = q.z, v.w = q.w;
-			asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(d4 + i), "v"(v) : "memory");
-		}
-		for (uint32_t f = (n4 << 2) + (uint32_t)lane; f < n; f += 64u)
-			__hip_atomic_store(reinterpret_cast<uint32_t *>(dst) + f, dm_f2u(src[f]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-	} else {
-		for (uint32_t i = (uint32_t)lane; i < n4; i += 64u) d4[i] = s4[i];
-		for (uint32_t f = (n4 << 2) + (uint32_t)lane; f < n; f += 64u) dst[f] = src[f];
-	}
-	asm volatile("" ::: "memory");
-}
-
-// wave-uniform bookkeeping of the two staged sub-jobs
-struct Stage {
-	uint32_t base0 = 0, base1 = 0;   // first item of the sub-job in buffer 0 / 1
-	uint32_t total0 = 0, total1 = 0; // its items (0 = buffer free)
-	uint32_t pend0 = 0, pend1 = 0;   // of those handed out, how many have not delivered their radiance yet
-};
-
-// A path has ended with radiance c: into its sub-job's staging slot if that sub-job is still staged,
-// else (its buffer was needed and written out meanwhile) straight to HBM. f0 / f1 report which.
-template <uint32_t SUB, bool WT = false>
-__device__ __forceinline__ void deliver(const Stage &st, float *__restrict__ stage, float *__restrict__ radiance, uint32_t item, f3 c, bool &f0, bool &f1 SRT_RC_PARAM) {
-	if (SRT_DIRECT_RADIANCE) {
-		typedef float f3v __attribute__((ext_vector_type(3)));
-		f3v v;
-		v.x = c.x, v.y = c.y, v.z = c.z;
-		float *g = radiance + 3ull * item;
-		if (SRT_DIRECT_STORE == 1) asm volatile("global_store_dwordx3 %0, %1, off sc1" : : "v"(g), "v"(v) : "memory");
-		else if (SRT_DIRECT_STORE == 2) asm volatile("global_store_dwordx3 %0, %1, off nt" : : "v"(g), "v"(v) : "memory");
-		else asm volatile("global_store_dwordx3 %0, %1, off" : : "v"(g), "v"(v) : "memory");
-		return;
-	}
-	const uint32_t d0 = item - st.base0, d1 = item - st.base1;
-	if (d0 < st.total0) {
-		float *s = stage + 3u * d0;
-		s[0] = c.x, s[1] = c.y, s[2] = c.z;
-		f0 = true;
-	} else if (d1 < st.total1) {
-		float *s = stage + 3u * (SUB + d1);
-		s[0] = c.x, s[1] = c.y, s[2] = c.z;
-		f1 = true;
-	} else {
-		SRT_REGION(HANDIN_ORPHAN);
-		// The path outlived its staging buffer, which has been written out with a stale value in this item's place: store
-		// the radiance directly -- after that earlier store of this wave has been acknowledged. The buffer left long ago
-		// (a path's life time ago), so the wait returns at once; it only pins the order.
-		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-		// ONE 12-byte store: three dword stores to a line that is not in cache cost three read-modify-write round trips
-		// to HBM (measured: 64 GB written per launch for 25.5 GB of radiance, 8 % of the paths taking this branch)
-		typedef float f3v __attribute__((ext_vector_type(3)));
-		f3v v;
-		v.x = c.x, v.y = c.y, v.z = c.z;
-		float *g = radiance + 3ull * item;
-		if (WT || SRT_ORPHAN_STORE == 1) asm volatile("global_store_dwordx3 %0, %1, off sc1" : : "v"(g), "v"(v) : "memory"); // (flush_stage)
-		else if (SRT_ORPHAN_STORE == 2) asm volatile("global_store_dwordx3 %0, %1, off nt" : : "v"(g), "v"(v) : "memory");
-		else asm volatile("global_store_dwordx3 %0, %1, off" : : "v"(g), "v"(v) : "memory");
-	}
+__device__ __forceinline__ void store_radiance(float *__restrict__ radiance, uint32_t item, f3 c) {
+	typedef float f3v __attribute__((ext_vector_type(3)));
+	f3v v;
+	v.x = c.x, v.y = c.y, v.z = c.z;
+	float *g = radiance + 3ull * item;
+	if (SRT_RADIANCE_STORE == 1) asm volatile("global_store_dwordx3 %0, %1, off sc1" : : "v"(g), "v"(v) : "memory");
+	else if (SRT_RADIANCE_STORE == 2) asm volatile("global_store_dwordx3 %0, %1, off nt" : : "v"(g), "v"(v) : "memory");
+	else asm volatile("global_store_dwordx3 %0, %1, off" : : "v"(g), "v"(v) : "memory");
 }
 
 // Evaluate the sky for the first n queued escapes (n <= 64), one per lane, and finish their
 // paths: mask *= sky; color += mask (render.cl:464-465). Called with all 64 lanes in
 // wave-uniform control flow.
-template <uint32_t SUB, bool WT = false>
-__device__ __forceinline__ void resolve_ring(const TraceParams &p, const float *__restrict__ ring, uint32_t n, Stage &st, float *__restrict__ stage, int lane SRT_RC_PARAM) {
+__device__ __forceinline__ void resolve_ring(const TraceParams &p, const float *__restrict__ ring, uint32_t n, int lane SRT_RC_PARAM) {
 	asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-	bool f0 = false, f1 = false;
 	if ((uint32_t)lane < n) {
 		SRT_REGION(SKY_RESOLVE);
 		constexpr uint32_t RC = SRT_RING_CAP;
@@ -1119,10 +1043,8 @@ __device__ __forceinline__ void resolve_ring(const TraceParams &p, const float *
 		const uint32_t item = dm_f2u(ring[9 * RC + lane]);
 		m = m * sky_box(p, d);
 		c = c + m;
-		deliver<SUB, WT>(st, stage, p.radiance, item, c, f0, f1 SRT_RC_ARG);
+		store_radiance(p.radiance, item, c);
 	}
-	st.pend0 -= (uint32_t)__popcll(ballot64(f0));
-	st.pend1 -= (uint32_t)__popcll(ballot64(f1));
 	asm volatile("" ::: "memory");
 }
 } // namespace
@@ -1202,13 +1124,11 @@ __global__ __launch_bounds__(64, USE_BVH ? SRT_TRACE_WAVES_PER_SIMD_BVH : HAS_MO
 		chunk_end = (total_items - chunk_cur < p.job_items) ? total_items : chunk_cur + p.job_items;
 	}
 	bool queue_dry = (total_items == 0);
-	Stage st;
-	uint32_t qpix0 = 0, qpix1 = 0, koff0 = 0, koff1 = 0; // pixel and sample offset of each staged sub-job's first item
-	uint32_t issued = 0, cur = 0;                        // items of buffer `cur` handed out so far
-	float *__restrict__ stage = reinterpret_cast<float *>(lds + p.stage_off); // [2][SUB] packed {r, g, b}
-	float *__restrict__ ring = stage + (SRT_DIRECT_RADIANCE ? 0u : 2u * SUB * 3u);                          // [10][64] escaped paths awaiting their sky lookup
-	float *__restrict__ hq = ring + 10u * (uint32_t)SRT_RING_CAP;                                 // [16..18][HQ] paths that hit, awaiting their bounce (FIFO)
-	constexpr uint32_t HQ = USE_BVH ? SRT_HQ_CAP_BVH : SRT_HQ_CAP;
+	// the sub-job being handed out (wave-uniform): items [sj_next, sj_end); sj_next is sample sj_off of packed pixel sj_qpix
+	uint32_t sj_next = 0, sj_end = 0, sj_off = 0, sj_qpix = 0;
+	float *__restrict__ ring = reinterpret_cast<float *>(lds + p.stage_off); // [10][64] escaped paths awaiting their sky lookup
+	float *__restrict__ hq = ring + 10u * (uint32_t)SRT_RING_CAP; // [16..18][HQ] paths that hit, awaiting their bounce (FIFO)
+	constexpr uint32_t HQ = USE_BVH ? SRT_HQ_CAP_BVH : HAS_MODELS ? SRT_HQ_CAP_MODELS : SRT_HQ_CAP;
 #ifdef SRT_REGION_COUNT
 	uint32_t *region_ctr = reinterpret_cast<uint32_t *>(hq + (HAS_MODELS ? (USE_BVH ? 18u : 17u) : 16u) * HQ);
 	for (int i = lane; i < 2 * SRT_REGION_MAX; i += 64) region_ctr[i] = 0u;
@@ -1226,7 +1146,6 @@ __global__ __launch_bounds__(64, USE_BVH ? SRT_TRACE_WAVES_PER_SIMD_BVH : HAS_MO
 	// (write-through), loads bypass the vector L1 (a slot is reused, and the L1 keeps no track of this CU's own stores) and
 	// wait for the wave's stores first (REFILL below).
 	constexpr bool SUSPEND = HAS_MODELS && (!USE_BVH || SRT_BVH_SUSPEND);
-	constexpr bool WT = SUSPEND || SRT_WT_ALL; // radiances leave through write-through stores (flush_stage)
 	constexpr uint32_t SQ = (uint32_t)SRT_SQ_CAP, PK = (uint32_t)SRT_PK_CAP;
 	float *__restrict__ sq_base = SUSPEND ? const_cast<float *>((const float *)SRT_COLD(p).scan_queue) + (size_t)SRT_POOL_CTL_WORDS + SRT_POOL_REC_FLOATS + (size_t)blockIdx.x * (size_t)SRT_SCAN_QUEUE_FLOATS : nullptr;
 	float *__restrict__ pk = sq_base + 2u * 20u * SQ;
@@ -1261,7 +1180,7 @@ __global__ __launch_bounds__(64, USE_BVH ? SRT_TRACE_WAVES_PER_SIMD_BVH : HAS_MO
 	// VGPRs); only the instrumented triangle counters stay per lane.
 	// (paths and sky lookups of a wave stay below the launch's 2^32 items; iterations are diagnostics)
 	unsigned long long w_rays = 0;
-	uint32_t w_sky = 0, w_paths = 0, w_orphans = 0, w_evict = 0, w_iter = 0, w_shade = 0;
+	uint32_t w_sky = 0, w_paths = 0, w_iter = 0, w_shade = 0;
 	uint32_t w_scans = 0, w_scan_lanes = 0; // SUSPEND diagnostics, per lane: triangle scans of big models this lane led / took part in
 	uint32_t n_tri = 0, n_tri_u = 0;
 	uint32_t idle_spins = 0;
@@ -1532,7 +1451,7 @@ __global__ __launch_bounds__(64, USE_BVH ? SRT_TRACE_WAVES_PER_SIMD_BVH : HAS_MO
 			const uint32_t n_miss = (uint32_t)__popcll(mm);
 			const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mm, 0u));
 			if (ring_count + n_miss > RC) { // does not fit: the sky lookups of what is queued first (ring_count lanes busy)
-				resolve_ring<SUB, WT>(p, ring, ring_count, st, stage, lane SRT_RC_ARG);
+				resolve_ring(p, ring, ring_count, lane SRT_RC_ARG);
 				ring_count = 0;
 			}
 			if (RC == 64u) {
@@ -1559,7 +1478,7 @@ __global__ __launch_bounds__(64, USE_BVH ? SRT_TRACE_WAVES_PER_SIMD_BVH : HAS_MO
 					ring_count += take;
 					done += take;
 					if (done < n_miss) {
-						resolve_ring<SUB, WT>(p, ring, ring_count, st, stage, lane SRT_RC_ARG);
+						resolve_ring(p, ring, ring_count, lane SRT_RC_ARG);
 						ring_count = 0;
 					}
 				}
@@ -1753,13 +1672,9 @@ __global__ __launch_bounds__(64, USE_BVH ? SRT_TRACE_WAVES_PER_SIMD_BVH : HAS_MO
 		}
 
 		// ---- paths that ended in this iteration hand in their radiance ----
-		if (any64(fin)) {
-			bool f0 = false, f1 = false;
+		if (fin) {
 			SRT_REGION(HANDIN);
-			if (fin) deliver<SUB, WT>(st, stage, p.radiance, item, color, f0, f1 SRT_RC_ARG);
-			const uint32_t n0 = (uint32_t)__popcll(ballot64(f0)), n1 = (uint32_t)__popcll(ballot64(f1));
-			st.pend0 -= n0, st.pend1 -= n1;
-			if (SRT_DIAG_ON) w_orphans += (uint32_t)__popcll(ballot64(fin)) - n0 - n1;
+			store_radiance(p.radiance, item, color);
 		}
 
 		SRT_CLK(4);
@@ -1783,16 +1698,8 @@ __global__ __launch_bounds__(64, USE_BVH ? SRT_TRACE_WAVES_PER_SIMD_BVH : HAS_MO
 				uint32_t *__restrict__ ctl = reinterpret_cast<uint32_t *>(SRT_COLD(p).scan_queue); // [0,1] records reserved, [2,3] blocks taken, [4] waves gone, [5,6] permits, [16 + stack * NB + block] records published
 				float *__restrict__ prec = SRT_COLD(p).scan_queue + SRT_POOL_CTL_WORDS; // [stack][block][field][64]
 				if (!pool_last && (sq_count0 | sq_count1) != 0u) {
-					// Whoever ends these paths stores their radiance straight to HBM: this wave's staged radiances -- stale values
-					// in those paths' places -- must be out before the rays are published (flush; fence; publish).
-					if (ring_count != 0u) {
-						resolve_ring<SUB, WT>(p, ring, ring_count, st, stage, lane SRT_RC_ARG);
-						ring_count = 0;
-					}
-					if (st.total0 != 0u) flush_stage<WT>(stage, p.radiance + 3ull * st.base0, st.total0, lane);
-					if (st.total1 != 0u) flush_stage<WT>(stage + SUB * 3u, p.radiance + 3ull * st.base1, st.total1, lane);
-					st.total0 = 0u, st.pend0 = 0u, st.total1 = 0u, st.pend1 = 0u;
-					asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // (also: this wave's own stack records have arrived)
+					// (whoever ends these paths stores their radiance; an item is stored once, so there is nothing of this wave's to order it behind)
+					asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // this wave's own stack records have arrived
 					for (uint32_t sid = 0; sid < 2u; sid++) {
 						const uint32_t k = sid ? sq_count1 : sq_count0;
 						if (k == 0u) continue;
@@ -1968,23 +1875,9 @@ __global__ __launch_bounds__(64, USE_BVH ? SRT_TRACE_WAVES_PER_SIMD_BVH : HAS_MO
 			uint32_t off = 0, qpix = 0;
 			while (given < n_free) {
 				SRT_REGION(REFILL_LOOP);
-				const uint32_t cur_total = cur ? st.total1 : st.total0;
-				if (issued == cur_total) {
+				if (sj_next == sj_end) {
 					SRT_REGION(REFILL_OPEN);
-					// the current sub-job is handed out (or there is none yet): open the next one in the other buffer
-					const uint32_t o = cur ^ 1u;
-					const uint32_t o_total = o ? st.total1 : st.total0;
-					if (o_total != 0u) {
-						SRT_REGION(REFILL_FLUSH);
-						// It still holds the sub-job before the current one: write it out. Paths of it that are still on
-						// their way (pend != 0) deliver to HBM themselves when they end (deliver() orders their stores
-						// behind this one).
-						const uint32_t o_pend = o ? st.pend1 : st.pend0;
-						flush_stage<WT>(stage + o * SUB * 3u, p.radiance + 3ull * (o ? st.base1 : st.base0), o_total, lane);
-						if (SRT_DIAG_ON && o_pend != 0u) w_evict++;
-						if (o) st.total1 = 0u, st.pend1 = 0u;
-						else st.total0 = 0u, st.pend0 = 0u;
-					}
+					// the current sub-job is handed out (or there is none yet): open the next one of the wave's chunk
 					if (chunk_cur == chunk_end) {
 						SRT_REGION(REFILL_CURSOR);
 						unsigned long long start = total_items;
@@ -2007,28 +1900,22 @@ __global__ __launch_bounds__(64, USE_BVH ? SRT_TRACE_WAVES_PER_SIMD_BVH : HAS_MO
 					const uint32_t left = chunk_end - chunk_cur;
 					const uint32_t n = left < SUB ? left : SUB;
 					const uint32_t q0 = chunk_cur / nbs; // one division per sub-job
-					const uint32_t k0 = chunk_cur - q0 * nbs;
-					if (o) st.base1 = chunk_cur, st.total1 = n, st.pend1 = 0u, qpix1 = q0, koff1 = k0;
-					else st.base0 = chunk_cur, st.total0 = n, st.pend0 = 0u, qpix0 = q0, koff0 = k0;
+					sj_next = chunk_cur, sj_end = chunk_cur + n, sj_qpix = q0, sj_off = chunk_cur - q0 * nbs;
 					chunk_cur += n;
-					cur = o;
-					issued = 0;
 					continue;
 				}
 				SRT_REGION(REFILL_TAKE);
-				const uint32_t avail = cur_total - issued;
+				const uint32_t avail = sj_end - sj_next;
 				const uint32_t take = avail < n_free - given ? avail : n_free - given;
 				if (!active && !got && rank >= given && rank < given + take) {
-					const uint32_t r = issued + (rank - given);
-					item = (cur ? st.base1 : st.base0) + r;
-					off = (cur ? koff1 : koff0) + r; // < nbs + SUB
-					qpix = cur ? qpix1 : qpix0;
+					const uint32_t r = rank - given;
+					item = sj_next + r;
+					off = sj_off + r; // < nbs + SUB
+					qpix = sj_qpix;
 					got = true;
 				}
-				issued += take;
+				sj_next += take, sj_off += take;
 				given += take;
-				if (cur) st.pend1 += take;
-				else st.pend0 += take;
 				w_paths += take;
 			}
 			n_active += given; // every lane served holds a camera ray from here on
@@ -2096,9 +1983,7 @@ __global__ __launch_bounds__(64, USE_BVH ? SRT_TRACE_WAVES_PER_SIMD_BVH : HAS_MO
 	}
 	// queue dry, no lane active, nothing parked: whatever is still staged is complete
 	SRT_REGION(EPILOGUE);
-	if (ring_count != 0u) resolve_ring<SUB, WT>(p, ring, ring_count, st, stage, lane SRT_RC_ARG);
-	if (st.total0 != 0u) flush_stage<WT>(stage, p.radiance + 3ull * st.base0, st.total0, lane);
-	if (st.total1 != 0u) flush_stage<WT>(stage + SUB * 3u, p.radiance + 3ull * st.base1, st.total1, lane);
+	if (ring_count != 0u) resolve_ring(p, ring, ring_count, lane SRT_RC_ARG);
 
 	// per-wave counters: this wave's own 64-byte line, no atomics (device_types.h)
 	unsigned long long t3 = COUNT_TRIS ? n_tri : w_scans, t4 = COUNT_TRIS ? n_tri_u : w_scan_lanes;
@@ -2123,7 +2008,6 @@ __global__ __launch_bounds__(64, USE_BVH ? SRT_TRACE_WAVES_PER_SIMD_BVH : HAS_MO
 			w[10] += w_pool_taken, w[11] += w_pool_given, w[12] += (unsigned long long)w_pool_taken * w_pool_taken, w[13] += w_pool_last_taken;
 #endif
 		}
-		w[5] += (unsigned long long)w_orphans + ((unsigned long long)w_evict << 40); // diagnostics (srt_debug_counters)
 		w[6] += w_iter;
 		w[7] += w_shade;
 #ifdef SRT_PHASE_CLOCK
@@ -2392,9 +2276,8 @@ int srt_bvh_suspends(void) { return SRT_BVH_SUSPEND; }
 int srt_sub_job_items(int has_models, int use_bvh) { return !has_models ? SRT_SUB_PLAIN : use_bvh ? SRT_SUB_BVH : SRT_SUB_MODELS; }
 
 int srt_trace_lds_floats(int has_models, int use_bvh) {
-	// two staging buffers of packed 12-byte items, the sky ring (10 fields), the hit queue (16..18 fields)
-	const int sub = srt_sub_job_items(has_models, use_bvh);
-	int n = (SRT_DIRECT_RADIANCE ? 0 : 2 * sub * 3) + 10 * SRT_RING_CAP + (has_models ? (use_bvh ? 18 * SRT_HQ_CAP_BVH : 17 * SRT_HQ_CAP) : 16 * SRT_HQ_CAP);
+	// the sky ring (10 fields), the hit queue (16..18 fields)
+	int n = 10 * SRT_RING_CAP + (has_models ? (use_bvh ? 18 * SRT_HQ_CAP_BVH : 17 * SRT_HQ_CAP_MODELS) : 16 * SRT_HQ_CAP);
 #ifdef SRT_REGION_COUNT
 	n += 2 * SRT_REGION_MAX; // (waves, lanes) per region
 #endif

@@ -1029,6 +1029,19 @@ __device__ __forceinline__ void store_radiance(float *__restrict__ radiance, uin
 	else asm volatile("global_store_dwordx3 %0, %1, off" : : "v"(g), "v"(v) : "memory");
 }
 
+// ---- lane sets as wave-uniform masks (round 4) --------------------------------------------------------------------------------
+// Which lanes hold a ray, hit, escaped, ended ... lives in scalar registers as 64-bit masks. A divergent region is entered
+// with in_mask(m) (llvm.amdgcn.inverse.ballot: the mask becomes the exec mask as it is), counts are s_bcnt1, ranks v_mbcnt, set
+// algebra is scalar. Rounds 1-3 kept per-lane bools across the phases of the main loop: every vote on such a bool is a
+// v_cndmask + v_cmp pair, every merge of two of them a chain of scalar mask instructions, and none of it is free -- measured in
+// place (scripts/r04_issue_cost.sh, profiles/r04_issue_cost.json) a scalar instruction costs the launch 1.0-1.3 v_add_f32.
+__device__ __forceinline__ bool in_mask(unsigned long long m) { return __builtin_amdgcn_inverse_ballot_w64(m); }
+__device__ __forceinline__ uint32_t popc64(unsigned long long m) { return (uint32_t)__builtin_popcountll(m); }
+__device__ __forceinline__ uint32_t lane_rank(unsigned long long m) { // set bits of m below this lane
+	return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+}
+__device__ __forceinline__ unsigned long long lanes_below(uint32_t n) { return n >= 64u ? ~0ull : ((1ull << n) - 1ull); } // lanes 0 .. n-1
+
 // Evaluate the sky for the first n queued escapes (n <= 64), one per lane, and finish their
 // paths: mask *= sky; color += mask (render.cl:464-465). Called with all 64 lanes in
 // wave-uniform control flow.
@@ -1172,10 +1185,10 @@ __global__ __launch_bounds__(64, USE_BVH ? SRT_TRACE_WAVES_PER_SIMD_BVH : HAS_MO
 	BvhStackEntry bvh_stack[USE_BVH ? SRT_BVH_STACK_CAP : 1]; // per lane, in scratch memory (walk_bvh)
 	const float4 *__restrict__ bvh_blocks = reinterpret_cast<const float4 *>(p.bvh_blocks);
 	uint32_t best_j = 0;   // BVH only: index inside the model
-	bool active = false;   // the lane holds a ray that awaits closest_intersection
+	unsigned long long actm = 0ull; // (wave-uniform) the lanes that hold a ray awaiting closest_intersection
+	unsigned long long resm = 0ull; // (wave-uniform) SUSPEND: of those, the rays taken back from a scan stack or the pool, which scan the model of their block `pos` now
 	float tmin = DM_INF_F; // closest hit so far of the ray under way (kept across a suspension)
 	uint32_t pos = 0;      // SUSPEND: first shape block this ray still has to see (0 = a fresh ray)
-	bool resumed = false;  // SUSPEND: the ray was taken back from the scan queue and scans the model of block `pos` now
 	// rays / sky / paths are counted per WAVE with popcounts of the exec mask (scalar adds, no
 	// VGPRs); only the instrumented triangle counters stay per lane.
 	// (paths and sky lookups of a wave stay below the launch's 2^32 items; iterations are diagnostics)
@@ -1184,14 +1197,17 @@ __global__ __launch_bounds__(64, USE_BVH ? SRT_TRACE_WAVES_PER_SIMD_BVH : HAS_MO
 	uint32_t w_scans = 0, w_scan_lanes = 0; // SUSPEND diagnostics, per lane: triangle scans of big models this lane led / took part in
 	uint32_t n_tri = 0, n_tri_u = 0;
 	uint32_t idle_spins = 0;
-	uint32_t n_active = 0; // wave-uniform: lanes with `active` set, as of the end of the last iteration
+	// SHADE runs when hits + queued paths exceed this: a full wave (or more than the queue holds); anything at all once the work cursor is dry
+	constexpr uint32_t SHADE_THR = ((uint32_t)SRT_SHADE_MIN - 1u) < HQ ? ((uint32_t)SRT_SHADE_MIN - 1u) : HQ;
+	uint32_t shade_thr = queue_dry ? 0u : SHADE_THR;
 
 	SRT_CLK_DECL;
 	SRT_REGION(PROLOGUE);
 	for (;;) {
 		SRT_REGION(LOOP_HEAD);
-		bool hit = false, missed = false, fin = false;
-		bool suspended0 = false, suspended1 = false; // SUSPEND: the lane's ray went to scan stack 0 / 1 in this iteration
+		unsigned long long hitm = 0ull, missm = 0ull, finm = 0ull; // (wave-uniform) lanes whose ray hit / escaped, whose path ended in this iteration
+		uint32_t susp = 0u; // SUSPEND, per lane: 1 + the scan stack the lane's ray went to in this iteration
+		int key = -1;       // per lane: >= 0 when the ray hit a shape that has a material
 		if (SRT_DIAG_ON) w_iter++;
 		SRT_CLK(6);
 #ifdef SRT_DUMMY_KIND
@@ -1250,31 +1266,30 @@ __global__ __launch_bounds__(64, USE_BVH ? SRT_TRACE_WAVES_PER_SIMD_BVH : HAS_MO
 		}
 #endif
 		// ================= EXTEND: closest_intersection (render.cl:293-378), winner deferred =================
-		if (n_active != 0u) { // lanes that hold a ray (counted at the end of the previous iteration: no vote here)
-			if (nb > 0) {
-				if (SUSPEND) w_rays += (unsigned long long)__popcll(ballot64(active && !resumed)); // a resumed ray was counted when it set out
-				else w_rays += n_active;
-			}
-			// Sphere / plane scenes: the tests run for all 64 lanes, the lanes without a ray compute on whatever they hold and are
-			// sorted out when hit / missed are set -- no exec-mask bookkeeping around the phase, and hit / missed come straight out
-			// of compares. (With models a lane without a ray must not scan or walk.)
+		if (actm != 0ull) {
 			constexpr bool MASKED = HAS_MODELS;
-			if (!MASKED || active) {
-				SRT_REGION(EXTEND_SETUP);
-				if (nb <= 0) { // render.cl:403: no bounce loop at all -> colour 0
-					fin = MASKED ? true : active;
-				} else {
-					if (!SUSPEND || !resumed) {
-						tmin = DM_INF_F;
-						best = -1;
-						best_tri = 0, best_j = 0;
-						pos = 0;
-					}
-					bool part = true;       // SUSPEND: false once the ray has gone to the scan queue
-					uint32_t sq_pushed0 = 0, sq_pushed1 = 0; // records pushed by this EXTEND phase so far. Uniform among the lanes in here only:
-					                                          // the counts, which the lanes outside this branch read too, are brought up to date after it
-					f3 inv = mk(0.f, 0.f, 0.f);
-					if (HAS_MODELS) inv = mk(1.0f / dir.x, 1.0f / dir.y, 1.0f / dir.z);
+			if (nb <= 0) { // render.cl:403: no bounce loop at all -> colour 0
+				finm = actm;
+			} else {
+				w_rays += SUSPEND ? popc64(actm & ~resm) : popc64(actm); // a resumed ray was counted when it set out
+				const bool resumed = SUSPEND ? in_mask(resm) : false;
+				// Sphere / plane scenes: the tests run for all 64 lanes, the lanes without a ray compute on whatever they hold and are
+				// sorted out by `actm` afterwards -- no exec-mask bookkeeping around the phase. (With models a lane without a ray must
+				// not scan or walk.)
+				if (!MASKED || in_mask(actm)) {
+					SRT_REGION(EXTEND_SETUP);
+					{
+						if (!SUSPEND || !resumed) {
+							tmin = DM_INF_F;
+							best = -1;
+							best_tri = 0, best_j = 0;
+							pos = 0;
+						}
+						bool part = true;       // SUSPEND: false once the ray has gone to the scan queue
+						uint32_t sq_pushed0 = 0, sq_pushed1 = 0; // records pushed by this EXTEND phase so far. Uniform among the lanes in here only:
+						                                          // the counts, which the lanes outside this branch read too, are brought up to date after it
+						f3 inv = mk(0.f, 0.f, 0.f);
+						if (HAS_MODELS) inv = mk(1.0f / dir.x, 1.0f / dir.y, 1.0f / dir.z);
 
 					// Blocks of same-type shapes in array order; header and data of the NEXT block are fetched (scalar
 					// loads, one allocated past the end) before this one is tested, so only the first block's load
@@ -1332,8 +1347,7 @@ __global__ __launch_bounds__(64, USE_BVH ? SRT_TRACE_WAVES_PER_SIMD_BVH : HAS_MO
 										sq[18 * SQ + e] = dm_u2f(bidx);
 										if (USE_BVH) sq[19 * SQ + e] = dm_u2f(best_j);
 										part = false;
-										if (sid) suspended1 = true;
-										else suspended0 = true;
+										susp = 1u + sid;
 									}
 									if (sid) sq_pushed1 += n_want;
 									else sq_pushed0 += n_want;
@@ -1418,45 +1432,45 @@ __global__ __launch_bounds__(64, USE_BVH ? SRT_TRACE_WAVES_PER_SIMD_BVH : HAS_MO
 						}
 					}
 					SRT_REGION(EXTEND_FINISH);
-					if (SUSPEND) resumed = false;
-					// a shape without a material counts as a miss (render.cl:404: material_index >= 0)
-					if (!SUSPEND || part) { // else: the ray waits in the scan queue, with all of its state
-						if (all_materials_ok) { // (wave-uniform) every shape of the scene has a material: no look-up, closest shape = hit
-							hit = best >= 0;
-						} else {
-							int material_index = -1;
-							if (best >= 0) material_index = USE_LDS ? (int)f2u(reinterpret_cast<const float *>(lds)[8 * best + 1]) : p.winners[best].material;
-							hit = material_index >= 0;
+						if (!SUSPEND || part) { // else: the ray waits in the scan queue, with all of its state
+							// a shape without a material counts as a miss (render.cl:404: material_index >= 0)
+							key = best;
+							if (!all_materials_ok) { // (wave-uniform; else every shape of the scene has a material: closest shape = hit)
+								key = -1;
+								if (best >= 0) key = USE_LDS ? (int)f2u(reinterpret_cast<const float *>(lds)[8 * best + 1]) : p.winners[best].material;
+							}
+							if (!MASKED) org = org + dir * tmin; // (a lane that hit nothing, or held no ray, has no further use for its origin)
+							else if (key >= 0) org = org + dir * tmin; // rayhit->position (render.cl:312,343,362)
 						}
-						if (!MASKED) hit = hit && active;
-						missed = MASKED ? !hit : (!hit && active);
-						if (!MASKED) org = org + dir * tmin; // (a lane that hit nothing, or held no ray, has no further use for its origin)
-						else if (hit) org = org + dir * tmin; // rayhit->position (render.cl:312,343,362)
 					}
 				}
-				active = false;
+				// wave-uniform again
+				hitm = ballot64(key >= 0) & actm;
+				missm = actm & ~hitm;
+				if (SUSPEND) {
+					const unsigned long long s0 = ballot64(susp == 1u), s1 = ballot64(susp == 2u); // went to scan stack 0 / 1: neither hit nor escaped yet
+					sq_count0 += popc64(s0), sq_count1 += popc64(s1);
+					missm &= ~(s0 | s1);
+					resm = 0ull;
+				}
 			}
+			actm = 0ull;
 		}
 
-		if (SUSPEND) { // wave-uniform again
-			sq_count0 += (uint32_t)__popcll(ballot64(suspended0));
-			sq_count1 += (uint32_t)__popcll(ballot64(suspended1));
-		}
 		SRT_CLK(0);
 		// ---- escaped paths queue for the sky (wave-uniform control flow) ----
-		const unsigned long long mm = ballot64(missed);
-		if (mm != 0ull) {
+		if (missm != 0ull) {
 			SRT_REGION(SKY_PUSH);
 			constexpr uint32_t RC = SRT_RING_CAP;
-			const uint32_t n_miss = (uint32_t)__popcll(mm);
-			const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mm, 0u));
+			const uint32_t n_miss = popc64(missm);
+			const uint32_t rank = lane_rank(missm);
 			if (ring_count + n_miss > RC) { // does not fit: the sky lookups of what is queued first (ring_count lanes busy)
 				resolve_ring(p, ring, ring_count, lane SRT_RC_ARG);
 				ring_count = 0;
 			}
 			if (RC == 64u) {
 				// an empty ring holds a whole wave's escapes: one round, no loop
-				if (missed) {
+				if (in_mask(missm)) {
 					const uint32_t e = ring_count + rank;
 					ring[0 * RC + e] = dir.x, ring[1 * RC + e] = dir.y, ring[2 * RC + e] = dir.z;
 					ring[3 * RC + e] = mask.x, ring[4 * RC + e] = mask.y, ring[5 * RC + e] = mask.z;
@@ -1465,6 +1479,7 @@ __global__ __launch_bounds__(64, USE_BVH ? SRT_TRACE_WAVES_PER_SIMD_BVH : HAS_MO
 				}
 				ring_count += n_miss;
 			} else {
+				const bool missed = in_mask(missm);
 				uint32_t done = 0;
 				while (done < n_miss) { // more lanes may have escaped than the ring holds
 					const uint32_t take = (RC - ring_count) < (n_miss - done) ? (RC - ring_count) : (n_miss - done);
@@ -1488,19 +1503,19 @@ __global__ __launch_bounds__(64, USE_BVH ? SRT_TRACE_WAVES_PER_SIMD_BVH : HAS_MO
 
 		SRT_CLK(1);
 		// ================= SHADE or PARK =================
-		const unsigned long long hb = ballot64(hit);
-		const uint32_t n_hit = (uint32_t)__popcll(hb);
+		const uint32_t n_hit = popc64(hitm);
 		const uint32_t n_ready = n_hit + hq_count;
-		if (n_ready >= (uint32_t)SRT_SHADE_MIN || n_ready > HQ || (queue_dry && n_ready > 0u)) {
+		if (n_ready > shade_thr) {
 			SRT_REGION(SHADE_HEAD);
-			// lanes without a hit take the oldest waiting paths
-			const uint32_t n_free = 64u - n_hit;
-			const uint32_t n_pop = n_free < hq_count ? n_free : hq_count;
+			unsigned long long shm = hitm; // the lanes that shade: those with a hit, and the free ones that take the oldest waiting paths
+			const uint32_t n_free_s = 64u - n_hit;
+			const uint32_t n_pop = n_free_s < hq_count ? n_free_s : hq_count;
 			if (n_pop != 0u) {
 				asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-				const unsigned long long fb = ~hb;
-				const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(fb >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)fb, 0u));
-				if (!hit && rank < n_pop) {
+				const unsigned long long fb = ~hitm;
+				const uint32_t rank = lane_rank(fb);
+				const unsigned long long popm = ballot64(rank < n_pop) & fb;
+				if (in_mask(popm)) {
 					SRT_REGION(SHADE_POP);
 					uint32_t e = hq_head + rank;
 					e = e >= HQ ? e - HQ : e;
@@ -1514,15 +1529,21 @@ __global__ __launch_bounds__(64, USE_BVH ? SRT_TRACE_WAVES_PER_SIMD_BVH : HAS_MO
 					item = dm_f2u(hq[15 * HQ + e]);
 					if (HAS_MODELS) best_tri = dm_f2u(hq[16 * HQ + e]);
 					if (USE_BVH) best_j = dm_f2u(hq[17 * HQ + e]);
-					hit = true;
 				}
 				asm volatile("" ::: "memory");
 				hq_head += n_pop;
 				hq_head = hq_head >= HQ ? hq_head - HQ : hq_head;
 				hq_count -= n_pop;
+				shm |= popm;
 			}
+			// render.cl:415-416: the last bounce only collects the emission. Lanes on their last bounce run the bounce below along
+			// with the others and drop what it computes (the wave pays for it either way; not masking them out saves the
+			// exec-mask bookkeeping and the copies of mask / direction the compiler keeps around such a branch) -- unless
+			// the whole wave is on its last bounce.
+			const unsigned long long lastm = ballot64(bounce == nb - 1) & shm;
+			const bool show_normals = p.rd.show_normals != 0;
 			if (SRT_DIAG_ON) w_shade++;
-			if (hit) {
+			if (in_mask(shm)) {
 				SRT_REGION(SHADE_WINNER);
 				// ---- winner: normal, material (render.cl:311-312,337-343,361-362,372-375); org = hit position ----
 				int type, material_index;
@@ -1575,9 +1596,8 @@ __global__ __launch_bounds__(64, USE_BVH ? SRT_TRACE_WAVES_PER_SIMD_BVH : HAS_MO
 				const bool front = dot3(nrm, dir) < 0.0f;
 				nrm = nrm * (front ? 1.0f : -1.0f);
 
-				if (p.rd.show_normals) {
+				if (show_normals) { // (wave-uniform)
 					color = mk(nrm.x * 0.5f + 0.5f, nrm.y * 0.5f + 0.5f, nrm.z * 0.5f + 0.5f); // render.cl:407-410
-					fin = true;
 				} else {
 					SRT_REGION(SHADE_MATERIAL);
 					float4 m0, m1, mc, me;
@@ -1592,13 +1612,7 @@ __global__ __launch_bounds__(64, USE_BVH ? SRT_TRACE_WAVES_PER_SIMD_BVH : HAS_MO
 					const float transmittance = m1.x, ior = m1.y;
 					const f3 mcolor = mk(mc.x, mc.y, mc.z);
 					color = color + (mask * mk(me.x, me.y, me.z)) * emission_strength; // render.cl:413
-					// render.cl:415-416: the last bounce only collects the emission. Lanes on their last bounce run the code below along
-					// with the others and drop what it computes (the wave pays for it either way; not masking them out saves the
-					// exec-mask bookkeeping and the copies of mask / direction the compiler keeps around such a branch) -- unless
-					// the whole wave is on its last bounce.
-					const bool last = bounce == nb - 1;
-					fin = last;
-					if (any64(!last)) {
+					if ((shm & ~lastm) != 0ull) { // (wave-uniform) somebody bounces on: see `lastm` above
 						SRT_REGION(SHADE_BOUNCE);
 						// cosine weighted direction: 6 draws (render.cl:421, 156-163)
 						f3 rd_ = normalize3(random_normal3(seed));
@@ -1644,16 +1658,22 @@ __global__ __launch_bounds__(64, USE_BVH ? SRT_TRACE_WAVES_PER_SIMD_BVH : HAS_MO
 						dir = normalize3(dir);
 						org = pos + (nrm * sign_fast(dot3(nrm, dir))) * 0.001f; // render.cl:462
 						bounce++;
-						active = !last;
 					}
 				}
+			}
+			// what became of the shaded paths: ended (show_normals, or the last bounce: only its emission counts) or on their way again
+			if (show_normals) {
+				finm |= shm;
+			} else {
+				finm |= lastm;
+				actm = shm & ~lastm;
 			}
 			SRT_CLK(2);
 		} else if (n_hit != 0u) {
 			// PARK: every hit waits in the queue; all lanes are free for new camera rays
-			if (hit) {
+			if (in_mask(hitm)) {
 				SRT_REGION(PARK);
-				uint32_t e = hq_head + hq_count + __builtin_amdgcn_mbcnt_hi((uint32_t)(hb >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)hb, 0u));
+				uint32_t e = hq_head + hq_count + lane_rank(hitm);
 				e = e >= HQ ? e - HQ : e;
 				hq[0 * HQ + e] = org.x, hq[1 * HQ + e] = org.y, hq[2 * HQ + e] = org.z;
 				hq[3 * HQ + e] = dir.x, hq[4 * HQ + e] = dir.y, hq[5 * HQ + e] = dir.z;
@@ -1672,23 +1692,23 @@ __global__ __launch_bounds__(64, USE_BVH ? SRT_TRACE_WAVES_PER_SIMD_BVH : HAS_MO
 		}
 
 		// ---- paths that ended in this iteration hand in their radiance ----
-		if (fin) {
-			SRT_REGION(HANDIN);
-			store_radiance(p.radiance, item, color);
+		if (finm != 0ull) {
+			if (in_mask(finm)) {
+				SRT_REGION(HANDIN);
+				store_radiance(p.radiance, item, color);
+			}
 		}
 
 		SRT_CLK(4);
 		// ================= REFILL: free lanes take new camera rays =================
 		SRT_REGION(REFILL_HEAD);
-		unsigned long long freeb = ballot64(!active);
-		uint32_t n_free = (uint32_t)__popcll(freeb);
-		n_active = 64u - n_free;
+		uint32_t n_act = popc64(actm); // lanes that hold a ray
 		if (SUSPEND) {
 			// A scan stack that holds a wave-full is taken back by ALL 64 lanes: the scan then runs without an idle lane. Rays the
 			// lanes hold at this point -- bounced or new, about to set out -- are parked and come back into lanes that fall free.
 			// At the very end (no camera ray left, nothing else under way) the fuller stack is taken back as it is.
 			const bool full0 = sq_count0 >= (uint32_t)SRT_SCAN_FULL, full1 = sq_count1 >= (uint32_t)SRT_SCAN_FULL;
-			const bool tail = queue_dry && n_active == 0u && hq_count == 0u && pk_count == 0u;
+			const bool tail = queue_dry && n_act == 0u && hq_count == 0u && pk_count == 0u;
 			auto ld = [&](const float *a) { return dm_u2f(__hip_atomic_load(reinterpret_cast<const uint32_t *>(a), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)); };
 			bool took_pool = false;
 			if (use_pool && tail && !full0 && !full1 && !pool_leave) {
@@ -1784,8 +1804,8 @@ __global__ __launch_bounds__(64, USE_BVH ? SRT_TRACE_WAVES_PER_SIMD_BVH : HAS_MO
 						}
 					}
 					const float *__restrict__ src = prec + ((size_t)got_sid * SRT_POOL_BLOCKS + got_blk) * (20u * 64u) + (uint32_t)lane;
-					active = (uint32_t)lane < got_cnt;
-					if (active) {
+					actm = lanes_below(got_cnt);
+					if (in_mask(actm)) {
 						org = mk(ld(src + 0 * 64), ld(src + 1 * 64), ld(src + 2 * 64));
 						dir = mk(ld(src + 3 * 64), ld(src + 4 * 64), ld(src + 5 * 64));
 						mask = mk(ld(src + 6 * 64), ld(src + 7 * 64), ld(src + 8 * 64));
@@ -1794,12 +1814,10 @@ __global__ __launch_bounds__(64, USE_BVH ? SRT_TRACE_WAVES_PER_SIMD_BVH : HAS_MO
 						tmin = ld(src + 15 * 64), best = (int)dm_f2u(ld(src + 16 * 64)), best_tri = dm_f2u(ld(src + 17 * 64));
 						pos = dm_f2u(ld(src + 18 * 64));
 						if (USE_BVH) best_j = dm_f2u(ld(src + 19 * 64));
-						resumed = true;
 					}
 					asm volatile("" ::: "memory");
-					n_active = got_cnt;
-					freeb = ballot64(!active);
-					n_free = 64u - got_cnt;
+					resm = actm;
+					n_act = got_cnt;
 					took_pool = true;
 					w_pool_taken++;
 					if (pool_last) w_pool_last_taken++;
@@ -1808,27 +1826,26 @@ __global__ __launch_bounds__(64, USE_BVH ? SRT_TRACE_WAVES_PER_SIMD_BVH : HAS_MO
 			const bool rest = tail && !took_pool && (sq_count0 | sq_count1) != 0u;
 			if (took_pool) {
 				// (the wave is full of rays from the pool)
-			} else if ((full0 || full1 || rest) && pk_count + n_active <= PK) {
+			} else if ((full0 || full1 || rest) && pk_count + n_act <= PK) {
 				SRT_REGION(REFILL_SCANQ);
-				if (n_active != 0u) {
-					const unsigned long long ab = ~freeb;
-					const uint32_t e = pk_count + __builtin_amdgcn_mbcnt_hi((uint32_t)(ab >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)ab, 0u));
-					if (active) {
+				if (n_act != 0u) {
+					const uint32_t e = pk_count + lane_rank(actm);
+					if (in_mask(actm)) {
 						pk[0 * PK + e] = org.x, pk[1 * PK + e] = org.y, pk[2 * PK + e] = org.z;
 						pk[3 * PK + e] = dir.x, pk[4 * PK + e] = dir.y, pk[5 * PK + e] = dir.z;
 						pk[6 * PK + e] = mask.x, pk[7 * PK + e] = mask.y, pk[8 * PK + e] = mask.z;
 						pk[9 * PK + e] = color.x, pk[10 * PK + e] = color.y, pk[11 * PK + e] = color.z;
 						pk[12 * PK + e] = dm_u2f(seed), pk[13 * PK + e] = dm_u2f((uint32_t)bounce), pk[14 * PK + e] = dm_u2f(item);
 					}
-					pk_count += n_active;
+					pk_count += n_act;
 				}
 				const uint32_t sid = full0 ? 0u : full1 ? 1u : (sq_count1 > sq_count0 ? 1u : 0u);
 				const uint32_t held = sid ? sq_count1 : sq_count0;
 				const uint32_t n_pop = held < 64u ? held : 64u;
 				const float *__restrict__ sq = sq_base + sid * (20u * SQ);
 				asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the records' stores have arrived (acknowledged by the L2)
-				active = (uint32_t)lane < n_pop;
-				if (active) {
+				actm = lanes_below(n_pop);
+				if (in_mask(actm)) {
 					const uint32_t e = held - 1u - (uint32_t)lane;
 					org = mk(ld(sq + 0 * SQ + e), ld(sq + 1 * SQ + e), ld(sq + 2 * SQ + e));
 					dir = mk(ld(sq + 3 * SQ + e), ld(sq + 4 * SQ + e), ld(sq + 5 * SQ + e));
@@ -1838,40 +1855,38 @@ __global__ __launch_bounds__(64, USE_BVH ? SRT_TRACE_WAVES_PER_SIMD_BVH : HAS_MO
 					tmin = ld(sq + 15 * SQ + e), best = (int)dm_f2u(ld(sq + 16 * SQ + e)), best_tri = dm_f2u(ld(sq + 17 * SQ + e));
 					pos = dm_f2u(ld(sq + 18 * SQ + e));
 					if (USE_BVH) best_j = dm_f2u(ld(sq + 19 * SQ + e));
-					resumed = true;
 				}
 				asm volatile("" ::: "memory");
+				resm = actm;
 				if (sid) sq_count1 -= n_pop;
 				else sq_count0 -= n_pop;
-				n_active = n_pop;
-				freeb = ballot64(!active);
-				n_free = 64u - n_pop;
-			} else if (pk_count != 0u && n_free != 0u) {
+				n_act = n_pop;
+			} else if (pk_count != 0u && n_act != 64u) {
 				SRT_REGION(REFILL_UNPARK);
 				asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-				const uint32_t n_pop = n_free < pk_count ? n_free : pk_count;
-				const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(freeb >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)freeb, 0u));
-				if (!active && rank < n_pop) {
+				const uint32_t n_pop = 64u - n_act < pk_count ? 64u - n_act : pk_count;
+				const unsigned long long fm = ~actm;
+				const uint32_t rank = lane_rank(fm);
+				const unsigned long long um = ballot64(rank < n_pop) & fm;
+				if (in_mask(um)) {
 					const uint32_t e = pk_count - 1u - rank;
 					org = mk(ld(pk + 0 * PK + e), ld(pk + 1 * PK + e), ld(pk + 2 * PK + e));
 					dir = mk(ld(pk + 3 * PK + e), ld(pk + 4 * PK + e), ld(pk + 5 * PK + e));
 					mask = mk(ld(pk + 6 * PK + e), ld(pk + 7 * PK + e), ld(pk + 8 * PK + e));
 					color = mk(ld(pk + 9 * PK + e), ld(pk + 10 * PK + e), ld(pk + 11 * PK + e));
 					seed = dm_f2u(ld(pk + 12 * PK + e)), bounce = (int)dm_f2u(ld(pk + 13 * PK + e)), item = dm_f2u(ld(pk + 14 * PK + e));
-					resumed = false;
-					active = true;
 				}
 				asm volatile("" ::: "memory");
 				pk_count -= n_pop;
-				n_active += n_pop;
-				freeb = ballot64(!active);
-				n_free -= n_pop;
+				actm |= um;
+				n_act += n_pop;
 			}
 		}
+		const uint32_t n_free = 64u - n_act;
 		if (!queue_dry && n_free >= (uint32_t)SRT_REFILL_MIN && (!SUSPEND || pk_count == 0u)) {
-			const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(freeb >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)freeb, 0u));
+			const unsigned long long freem = ~actm;
+			const uint32_t rank = lane_rank(freem);
 			uint32_t given = 0; // free lanes served so far (wave-uniform)
-			bool got = false;
 			uint32_t off = 0, qpix = 0;
 			while (given < n_free) {
 				SRT_REGION(REFILL_LOOP);
@@ -1891,6 +1906,7 @@ __global__ __launch_bounds__(64, USE_BVH ? SRT_TRACE_WAVES_PER_SIMD_BVH : HAS_MO
 						}
 						if (start >= (unsigned long long)total_items) {
 							queue_dry = true;
+							shade_thr = 0u;
 							break;
 						}
 						chunk_cur = (uint32_t)start;
@@ -1907,19 +1923,20 @@ __global__ __launch_bounds__(64, USE_BVH ? SRT_TRACE_WAVES_PER_SIMD_BVH : HAS_MO
 				SRT_REGION(REFILL_TAKE);
 				const uint32_t avail = sj_end - sj_next;
 				const uint32_t take = avail < n_free - given ? avail : n_free - given;
-				if (!active && !got && rank >= given && rank < given + take) {
-					const uint32_t r = rank - given;
+				const uint32_t r = rank - given; // (rank < given: a huge number)
+				const unsigned long long takem = ballot64(r < take) & freem; // the free lanes number given .. given + take - 1
+				if (in_mask(takem)) {
 					item = sj_next + r;
 					off = sj_off + r; // < nbs + SUB
 					qpix = sj_qpix;
-					got = true;
 				}
 				sj_next += take, sj_off += take;
 				given += take;
 				w_paths += take;
 			}
-			n_active += given; // every lane served holds a camera ray from here on
-			if (got) {
+			const unsigned long long gotm = ballot64(rank < given) & freem; // every lane served holds a camera ray from here on
+			actm |= gotm;
+			if (in_mask(gotm)) {
 				SRT_REGION(CAMERA);
 				// ---- camera ray (render.cl:488,496-516) ----
 				// No per-lane integer division and no IEEE division sequence here: pixel, row and sample come from multiplications
@@ -1964,24 +1981,25 @@ __global__ __launch_bounds__(64, USE_BVH ? SRT_TRACE_WAVES_PER_SIMD_BVH : HAS_MO
 				mask = mk(1.f, 1.f, 1.f);
 				color = mk(0.f, 0.f, 0.f);
 				bounce = 0;
-				active = true;
 			}
 		}
 
 		SRT_CLK(5);
 		SRT_REGION(LOOP_TAIL);
-		if (n_active == 0u && hq_count == 0u && (sq_count0 | sq_count1 | pk_count) == 0u) {
-			if (queue_dry && (!use_pool || pool_leave || pool_last)) break; // (with a pool: not before the wave has signed off, REFILL above)
-			// Bounded: a wave that spins here without ever getting work leaves with the watchdog counter set instead of hanging.
-			if (++idle_spins > (1u << 20)) {
-				if (lane == 0) atomicAdd((unsigned long long *)SRT_COLD(p).counters + SRT_CTR_WATCHDOG, 1ull);
-				break;
+		if (queue_dry) { // (wave-uniform; while the cursor has work a wave always holds some)
+			if (actm == 0ull && hq_count == 0u && (sq_count0 | sq_count1 | pk_count) == 0u) {
+				if (!use_pool || pool_leave || pool_last) break; // (with a pool: not before the wave has signed off, REFILL above)
+				// Bounded: a wave that spins here without ever getting work leaves with the watchdog counter set instead of hanging.
+				if (++idle_spins > (1u << 20)) {
+					if (lane == 0) atomicAdd((unsigned long long *)SRT_COLD(p).counters + SRT_CTR_WATCHDOG, 1ull);
+					break;
+				}
+			} else {
+				idle_spins = 0;
 			}
-		} else {
-			idle_spins = 0;
 		}
 	}
-	// queue dry, no lane active, nothing parked: whatever is still staged is complete
+	// queue dry, no lane holds a ray, nothing parked: the escapes still in the ring are what is left
 	SRT_REGION(EPILOGUE);
 	if (ring_count != 0u) resolve_ring(p, ring, ring_count, lane SRT_RC_ARG);
 

@@ -178,8 +178,9 @@ def cpu_baseline(name, sky, target_seconds=15.0, spp_override=0):
             same = same and bool(np.array_equal(np.isnan(a), np.isnan(b)) and np.array_equal(a.view(np.uint32)[~np.isnan(a)], b.view(np.uint32)[~np.isnan(b)]))
         n_rows = sum(y1 - y0 for y0, y1 in bands)
         return {
-            "value": round(rays / dt_ref / 1e6, 3), "unit": "Mray/s", "cores": threads, "cpu_model": cpu_model(), "kind": "reference", "_port_rows": port_rows,
-            "sample": f"oracle/_ref/libsrt_ref.so (the reference's src/render.cl compiled for x86-64, OpenMP over pixels), {len(bands)} bands of {band} rows spread over the frame ({n_rows} of {h} rows x {w} px x {spp} spp = {paths} paths, {rays} rays counted by the port on the same rows) in {dt_ref:.1f} s; the port took {dt_port:.1f} s on the same rows and its canvas is {'bit-identical' if same else 'DIFFERENT'}",
+            "value": round(rays / dt_ref / 1e6, 3), "unit": "Mray/s", "cores": threads, "threads": threads, "host_cores": cores, "cpu_model": cpu_model(), "kind": "reference", "_port_rows": port_rows,
+            "cores_is": "the threads that ran (OpenMP over pixels, capped at 64); host_cores = the cores this process may use",
+            "sample": f"oracle/_ref/libsrt_ref.so (the reference's src/render.cl compiled for x86-64 with ROCm clang; its 18 OpenCL built-ins -- cos, log, pow, atan2pi, normalize, dot, cross, mix, read_imagef ... -- are THIS repo's csrc/detmath.h through oracle/cl_builtins_shim.cpp, not an OpenCL runtime's; OpenMP over pixels), {len(bands)} bands of {band} rows spread over the frame ({n_rows} of {h} rows x {w} px x {spp} spp = {paths} paths, {rays} rays counted by the port on the same rows) in {dt_ref:.1f} s; the port took {dt_port:.1f} s on the same rows and its canvas is {'bit-identical' if same else 'DIFFERENT'}",
             "mpath_per_s": round(paths / dt_ref / 1e6, 3), "port_value": round(rays / dt_port / 1e6, 3), "reference_equals_port": same,
         }
     rows_wanted = int(max(1, min(h, target_seconds * paths_per_s / (w * spp))))
@@ -191,7 +192,8 @@ def cpu_baseline(name, sky, target_seconds=15.0, spp_override=0):
     n_rows = len(range(y0, h, stride))
     port_rows = {(y, y + 1): cp[y:y + 1, :, :3].copy() for y in range(y0, h, stride)}
     return {
-        "value": round(c["rays"] / dt / 1e6, 3), "unit": "Mray/s", "cores": threads, "cpu_model": cpu_model(), "kind": "port", "_port_rows": port_rows,
+        "value": round(c["rays"] / dt / 1e6, 3), "unit": "Mray/s", "cores": threads, "threads": threads, "host_cores": cores, "cpu_model": cpu_model(), "kind": "port", "_port_rows": port_rows,
+        "cores_is": "the threads that ran (OpenMP over pixels, capped at 64); host_cores = the cores this process may use",
         "sample": f"oracle/srt_oracle.c (bit-identical port of render.cl), rows {y0}::{stride} ({n_rows} of {h} rows x {w} px x {spp} spp = {c['paths']} paths, {c['rays']} rays) in {dt:.1f} s",
         "mpath_per_s": round(c["paths"] / dt / 1e6, 3),
     }
@@ -203,7 +205,7 @@ def kernels_hash():
     return hashlib.sha256((ROOT / "simple-raytracer_amd" / "csrc" / "kernels.hip").read_bytes()).hexdigest()
 
 
-def measure_config(name, sky, accel, steps, warmup, device):
+def measure_config(name, sky, accel, steps, warmup, device, keep_canvas=False):
     """One BASELINE config on one GPU through a handle of its own, outside the headline's timed region: ms per step (wall,
     outputs resident), the trace kernel's own time (HIP events), Mray/s, and the VALU roofline fraction where W_ops is defined
     (array-order scan: triangle counters from the instrumented kernel variant, one extra untimed dispatch)."""
@@ -216,21 +218,31 @@ def measure_config(name, sky, accel, steps, warmup, device):
     if accel == "bvh":
         t.set_acceleration(T.ACCEL_BVH)
     t.update_scene(shapes, tris, mats)
-    for _ in range(warmup):
-        t.clear_canvas(); t.trace(); t.resolve(1)
-    t.synchronize()
-    t.reset_counters()
-    kms, walls = [], []
-    for _ in range(steps):
-        t0 = time.perf_counter()
+    # Warm up by TIME as well as by count: at least `warmup` steps and at least 100 ms of launches. A 0.2 ms step measured two
+    # launches after the handle's first use still has first-use costs in it (round 3's driver run: one step of configs[0] took
+    # 74.7 ms with 0.15 ms inside the kernel's events; scripts/bench_stall_probe.py).
+    t_w, n_w = time.perf_counter(), 0
+    while n_w < warmup or (n_w < 2000 and time.perf_counter() - t_w < 0.1):
         t.clear_canvas(); t.trace(); t.resolve(1)
         t.synchronize()
-        walls.append(time.perf_counter() - t0)
+        n_w += 1
+    t.reset_counters()
+    kms, walls, calls = [], [], []
+    for _ in range(steps):
+        t0 = time.perf_counter()
+        t.clear_canvas()
+        t1 = time.perf_counter()
+        t.trace()
+        t2 = time.perf_counter()
+        t.resolve(1)
+        t3 = time.perf_counter()
+        t.synchronize()
+        t4 = time.perf_counter()
+        walls.append(t4 - t0)
+        calls.append((t1 - t0, t2 - t1, t3 - t2, t4 - t3))
         kms.append(t.last_trace_kernel_ms())
-    # the MEDIAN step (wall and kernel time alike): this runs in the process that has just released the headline's 25 GB, and
-    # one step of a 0.2 ms config that catches the device at it (seen: 75-80 ms between the launch's two events) would
-    # otherwise be the whole average
     dt = float(np.median(walls))
+    worst = int(np.argmax(walls))
     c = t.counters()
     launches, overlapped = t.last_trace_launches()
     per = {"rays": c["rays"] // steps, "paths": c["paths"] // steps, "sky": c["sky"] // steps, "tri_tests": 0, "tri_pass_u": 0}
@@ -245,9 +257,15 @@ def measure_config(name, sky, accel, steps, warmup, device):
         frac = round(w_ops(per, shapes) / (float(np.median(kms)) * 1e-3) / VALU_PEAK_LANE_OPS, 4)
     out = {"workload": desc + (" [BVH, srt_set_acceleration]" if accel == "bvh" else ""), "steps": steps, "ms_per_step": round(dt * 1e3, 3), "ms_per_step_is": "median of the steps' wall times", "ms_per_step_max": round(max(walls) * 1e3, 3),
            "kernel_ms": round(float(np.median(kms)), 3), "kernel_ms_max": round(float(max(kms)), 3), "kernel_ms_is": ("span of overlapping sample-batch launches" if overlapped else "sum of the launches' own durations") + " (median step)",
-           "launches_per_step": launches, "mray_s": round(per["rays"] / dt / 1e6, 1), "rays_per_step": per["rays"], "frac": frac}
+           "launches_per_step": launches, "mray_s": round(per["rays"] / dt / 1e6, 1), "rays_per_step": per["rays"], "frac": frac,
+           "warmup_steps": n_w, "watchdog": c["watchdog"],
+           "slowest_step_host_ms": dict(zip(("clear_canvas", "trace", "resolve", "synchronize"), [round(x * 1e3, 3) for x in calls[worst]]))}
+    if frac is not None:
+        out["frac_is"] = "ALGORITHMIC W_ops (SURVEY 8d: every ray x shape test at its full cost) / kernel time / VALU peak -- not executed VALU: the kernels skip work the formula charges (division-free triangle rejects, pre-transformed triangles), so it can approach or pass 1 without the pipe being full"
     if accel == "bvh":
         out["frac_note"] = "W_ops (SURVEY 8d) has no term for hierarchy steps: no roofline fraction for the BVH walk"
+    if keep_canvas:
+        out["_canvas"] = t.read_canvas()
     t.close()
     return out
 
@@ -513,6 +531,32 @@ def main():
         if check is not None:
             line["gathered_equals_single_gpu"] = check
             ok = ok and check
+        if world == 1 and args.workload == "spheres_1080p_1024spp" and not args.spp and not args.no_other_configs:
+            # The other BASELINE configs on this GPU (handles of their own; headline fields unchanged): right behind the headline's
+            # timed region, while the device is busy and BEFORE anything is freed or the CPU baseline leaves it idle for 15 s --
+            # round 3 measured them after both and one 0.2 ms step took 74.7 ms.
+            others, canv = [], {}
+            for name, accel, k, wu in (("spheres_256_16spp", "none", 20, 2), ("meshes_1080p_512spp", "none", 3, 1), ("meshes_1080p_512spp", "bvh", 3, 1),
+                                       ("mesh100k_1080p_256spp", "bvh", 3, 1), ("mesh100k_1080p_256spp", "none", 1, 0), ("spheres_4k_4096spp", "none", 1, 1)):  # (configs[3]: one warm-up step, which also allocates its 2 x 48 GB of radiance)
+                try:
+                    o = measure_config(name, sky, accel, k, wu, local_rank, keep_canvas=name.startswith("mesh"))
+                    if "_canvas" in o:
+                        canv[(name, accel)] = o.pop("_canvas")
+                    others.append(o)
+                except Exception as e:  # the headline line is still written
+                    others.append({"workload": name, "accel": accel, "error": str(e)})
+            # The full-size array scans run ~5,000 waves through the launch-end ray pool (kernels.hip REFILL_POOL), more than any
+            # test does: their canvases must equal the BVH's of the same frame bit for bit (same triangle test, same tie rule),
+            # and no wave may have hit a watchdog.
+            for o in others:
+                for name in ("meshes_1080p_512spp", "mesh100k_1080p_256spp"):
+                    if o.get("workload", "").startswith(WORKLOADS[name][5]) and "BVH" not in o["workload"] and (name, "none") in canv and (name, "bvh") in canv:
+                        o["canvas_equals_bvh_canvas"] = same_bits(canv[(name, "none")][..., :3], canv[(name, "bvh")][..., :3])
+                        ok = ok and o["canvas_equals_bvh_canvas"]
+                if o.get("watchdog"):
+                    ok = False
+            del canv
+            line["other_configs"] = others
         if world == 1 and not args.no_cpu_baseline:
             cb = cpu_baseline(args.workload, sky, spp_override=args.spp)
             # the frame that was TIMED, checked where the CPU has already rendered it: the canvas of the last timed step
@@ -523,26 +567,12 @@ def main():
             cb["gpu_rows_checked"] = int(sum(y1 - y0 for y0, y1 in port_rows))
             line["cpu_baseline"] = cb
             ok = ok and cb["gpu_equals_port"] and cb.get("reference_equals_port", True)
-        if world == 1 and args.workload == "spheres_1080p_1024spp" and not args.spp and not args.no_other_configs:
-            # the other BASELINE configs on this GPU, after the headline's timed region (handles of their own; headline fields unchanged)
-            t.close()
-            t = None
-            del canvas_t
-            torch.cuda.empty_cache()
-            others = []
-            for name, accel, k, wu in (("spheres_256_16spp", "none", 20, 2), ("meshes_1080p_512spp", "none", 3, 1), ("meshes_1080p_512spp", "bvh", 3, 1),
-                                       ("mesh100k_1080p_256spp", "bvh", 3, 1), ("mesh100k_1080p_256spp", "none", 1, 0), ("spheres_4k_4096spp", "none", 1, 1)):  # (configs[3]: one warm-up step, which also allocates its 2 x 48 GB of radiance)
-                try:
-                    others.append(measure_config(name, sky, accel, k, wu, local_rank))
-                except Exception as e:  # the headline line is still written
-                    others.append({"workload": name, "accel": accel, "error": str(e)})
-            line["other_configs"] = others
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(line) + "\n").encode())
         if not ok:
             if t is not None:
                 t.close()
-            raise SystemExit("bench.py: the timed canvas differs from its checker (see gpu_equals_port / gathered_equals_single_gpu in the line above)")
+            raise SystemExit("bench.py: a canvas differs from its checker, or a wave hit a watchdog (see gpu_equals_port / gathered_equals_single_gpu / other_configs[*].canvas_equals_bvh_canvas, watchdog in the line above)")
     if t is not None:
         t.close()
     if collect:

@@ -273,7 +273,8 @@ int srt_pipeline_flush(srt_tracer *t, uint8_t *argb_out, long long *frame_delive
  * specialisations against their generic definitions (must be 0); out[3..7] = sums of the
  * result bit patterns of detmath's log, cos, sqrt, atan2pi, pow on the device, to be
  * compared with the same sums from the host build of csrc/detmath.h; out[8], out[10] = mismatch
- * counts of the kernel's shared-reciprocal division and its unguarded Box-Muller square root
+ * counts of the kernel's shared-reciprocal division (both forms: the reciprocal refined on the device, and the host's
+ * rounded reciprocal of a sphere's radius with its out-of-range marker 0) and its unguarded Box-Muller square root
  * against IEEE `/` and sqrt (must be 0); out[9] = sum of the result bits of the built-in
  * normalize (detmath's division-free rsqrt), again for comparison with the host build; out[11] = mismatch count of the
  * RNG-scaling shortcuts (log of the raw count, theta from the raw count) against the plain forms

@@ -86,6 +86,20 @@ def _build_lock():
             fcntl.flock(f, fcntl.LOCK_UN)
 
 
+DEV_LIB = LIBDIR / "variants" / "dev" / "libsrt_hip.so"
+
+
+def build_dev(force=False):
+    """The -DSRT_DEV_KNOBS build of the same sources -> lib/variants/dev/libsrt_hip.so: reads the development knobs
+    (SRT_WAVES_PER_CU, SRT_SCAN_PAIRS, SRT_JOB_CAP_SUBS, SRT_POOL_BLOCKS, SRT_NO_SCAN_POOL) from the environment, which the
+    product library does not. For the tests that force rare paths and for scripts/."""
+    deps = [CSRC / s for s in SOURCES] + [(CSRC / h).resolve() for h in HEADERS] + [Path(__file__)]
+    if not force and DEV_LIB.exists() and all(d.stat().st_mtime <= DEV_LIB.stat().st_mtime for d in deps):
+        return DEV_LIB
+    with _build_lock():
+        return build_variant("dev", ["-DSRT_DEV_KNOBS"])
+
+
 def build_variant(name, extra_flags):
     """A/B experiments: the same sources with extra -D flags -> lib/variants/<name>/libsrt_hip.so."""
     out = LIBDIR / "variants" / name

@@ -122,7 +122,7 @@ struct TraceParams {
 	int32_t rank, world, rows_per_block, owned_rows;
 	int32_t use_bvh;          /* model records carry a BVH root instead of a first world triangle */
 	const float *bvh_blocks;  /* all models' 128-byte blocks (wide hierarchy above) */
-	float *scan_queue;        /* array scan: SRT_POOL_CTL_WORDS words of pool control (zeroed before the launch), SRT_POOL_REC_FLOATS of pool records, then
+	float *scan_queue;        /* array scan: SRT_POOL_CTL_WORDS words of pool control (zeroed before the launch), SRT_POOL_REC_FLOATS of pool records (only when pool_blocks != 0), then
 	                             SRT_SCAN_QUEUE_FLOATS per persistent wave (rays that wait for a big model's triangle scan, parked rays) */
 	/* camera-ray set-up without per-lane integer or IEEE divisions (kernels.hip CAMERA; srt_abi.hip fills them per launch) */
 	float inv_f_width, inv_f_height;  /* 1.0f / f_width, 1.0f / f_height, correctly rounded on the host (srt_div_by_rcp in kernels.hip) */
@@ -191,7 +191,7 @@ int srt_scan_queue_in_hbm(void); /* 1: TraceParams.scan_queue must point at SRT_
 #define SRT_POOL_BLOCKS 8192 /* per stack: 524,288 rays (a launch's ~5,000 waves hand in fewer than 64 each, and again after each bounce) */
 #define SRT_POOL_CTL_WORDS (16 + 2 * SRT_POOL_BLOCKS)
 #define SRT_POOL_REC_FLOATS ((size_t)2 * SRT_POOL_BLOCKS * 20 * 64)
-#define SRT_SCAN_SET_FLOATS(waves) ((size_t)SRT_POOL_CTL_WORDS + SRT_POOL_REC_FLOATS + (size_t)(waves) * SRT_SCAN_QUEUE_FLOATS) /* one set; a multiple of 4 */
+#define SRT_SCAN_SET_FLOATS(waves, pool) ((size_t)SRT_POOL_CTL_WORDS + ((pool) ? SRT_POOL_REC_FLOATS : (size_t)0) + (size_t)(waves) * SRT_SCAN_QUEUE_FLOATS) /* one set (pool: with the launch-end ray pool's records, 84 MB; TraceParams.pool_blocks != 0); a multiple of 4 */
 int srt_bvh_suspends(void);
 void srt_launch_prepass(const PrepassParams &p, uint64_t total_wtris, void *stream);
 void srt_launch_resolve(const ResolveParams &p, void *stream);

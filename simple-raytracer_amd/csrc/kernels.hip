@@ -1160,7 +1160,7 @@ __global__ __launch_bounds__(64, USE_BVH ? SRT_TRACE_WAVES_PER_SIMD_BVH : HAS_MO
 	// wait for the wave's stores first (REFILL below).
 	constexpr bool SUSPEND = HAS_MODELS && (!USE_BVH || SRT_BVH_SUSPEND);
 	constexpr uint32_t SQ = (uint32_t)SRT_SQ_CAP, PK = (uint32_t)SRT_PK_CAP;
-	float *__restrict__ sq_base = SUSPEND ? const_cast<float *>((const float *)SRT_COLD(p).scan_queue) + (size_t)SRT_POOL_CTL_WORDS + SRT_POOL_REC_FLOATS + (size_t)blockIdx.x * (size_t)SRT_SCAN_QUEUE_FLOATS : nullptr;
+	float *__restrict__ sq_base = SUSPEND ? const_cast<float *>((const float *)SRT_COLD(p).scan_queue) + (size_t)SRT_POOL_CTL_WORDS + (SRT_COLD(p).pool_blocks != 0u ? SRT_POOL_REC_FLOATS : (size_t)0) + (size_t)blockIdx.x * (size_t)SRT_SCAN_QUEUE_FLOATS : nullptr;
 	float *__restrict__ pk = sq_base + 2u * 20u * SQ;
 	uint32_t sq_count0 = 0, sq_count1 = 0, pk_count = 0; // wave-uniform
 	// The END of a launch: a wave that has run out of camera rays holds a remainder of fewer than 64 rays per stack, and every
@@ -1803,6 +1803,9 @@ __global__ __launch_bounds__(64, USE_BVH ? SRT_TRACE_WAVES_PER_SIMD_BVH : HAS_MO
 							break;
 						}
 					}
+					// The records are read only behind the count that publishes them: nothing lets the compiler move the (relaxed) loads
+					// below in front of the loop's, but nothing forbade it either. (The hardware returns a wave's loads in order.)
+					asm volatile("" ::: "memory");
 					const float *__restrict__ src = prec + ((size_t)got_sid * SRT_POOL_BLOCKS + got_blk) * (20u * 64u) + (uint32_t)lane;
 					actm = lanes_below(got_cnt);
 					if (in_mask(actm)) {
@@ -1945,6 +1948,7 @@ __global__ __launch_bounds__(64, USE_BVH ? SRT_TRACE_WAVES_PER_SIMD_BVH : HAS_MO
 #ifndef SRT_NO_CAMERA_DIET
 				// off < nbs + SUB: one pixel further at most when a pixel has at least SUB samples in this batch, else off / nbs by a
 				// 16-bit reciprocal (exact below 256 for divisors below 128: the error off * (magic * nbs - 2^16) stays under 2^15)
+				static_assert(SUB <= 128u, "off / nbs by the 16-bit reciprocal is exact for off < 256 and nbs < 128 only (tests/csrc/magic_check.cpp)");
 				const uint32_t dq = (nbs >= SUB) ? (off >= nbs ? 1u : 0u) : (off * c.nbs_magic16) >> 16;
 				const uint32_t q = qpix + dq; // owned pixels < 2^31 (checked by the host)
 				const uint32_t sample = c.first_sample + (off - dq * nbs);
@@ -2171,7 +2175,7 @@ __global__ __launch_bounds__(256) void srt_resolve_kernel(const ResolveParams p)
 //   out[2] cos_2pi(t) != dm_cosf(t), t = 2pi*u    out[3] sum of bits of dm_logf(u)
 //   out[4] sum of bits of dm_cosf(t)              out[5] sum of bits of sqrt(u)
 //   out[6] sum of bits of dm_atan2pif(u - 0.5, 0.37 - u)   out[7] sum of bits of dm_powf(u, 25)
-//   out[8] div3(a, b) != a / b          out[9] sum of bits of normalize(u - 0.5, 0.37 - u, (r & 0xffff) * 1e-3 - 30)
+//   out[8] div3(a, b) != a / b, or div3_by_rcp(a, b, RN(1 / b) or 0) != a / b          out[9] sum of bits of normalize(u - 0.5, 0.37 - u, (r & 0xffff) * 1e-3 - 30)
 //          (a, b: random mantissas and signs, exponents straddling the fast paths' guards,
 //           zero components mixed in)
 //   out[10] Box-Muller's rho as random_normal computes it (sqrt_rsq_zero_ok of -2 log of the raw count, u = 0 selected to +inf)
@@ -2251,8 +2255,14 @@ __global__ __launch_bounds__(256) void srt_selftest_kernel(unsigned long long *o
 		if ((r & 15u) == 3u) a.x = 0.0f;
 		if ((r & 31u) == 5u) a.y = -0.0f;
 		if ((r & 0xfffu) == 7u) a.z = dm_u2f(mix32(h)); // any bit pattern: denormals, inf, NaN
-		const float b = rand_float_exp(h, 127 - 44, 88);
+		float b = rand_float_exp(h, 127 - 44, 88);
+		if ((r & 0xffffu) == 11u) b = dm_u2f(0x7fc00000u | (mix32(h) & 0x3fffffu)); // a NaN denominator now and then
 		bad_div += same_f3(div3(a, b), a / b) ? 0 : 1;
+		{ // the sphere normal's form: the host's correctly rounded 1 / b for b in [2^-40, 2^40], else 0 (WinnerRec.inv_w, srt_abi.hip)
+			const float ab = dm_fabs(b);
+			const float y = (ab >= 0x1p-40f && ab <= 0x1p40f) ? 1.0f / b : 0.0f;
+			bad_div += same_f3(div3_by_rcp(a, b, y), a / b) ? 0 : 1;
+		}
 		// the built-in normalize on a vector made from r with plain float operations: checksum against the host build
 		const f3 nv = normalize3(mk(u - 0.5f, 0.37f - u, (float)(r & 0xffffu) * 1e-3f - 30.0f));
 		bad_norm += canon_bits(nv.x) + canon_bits(nv.y) + canon_bits(nv.z);

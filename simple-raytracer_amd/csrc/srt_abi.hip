@@ -419,7 +419,13 @@ int srt_fail(srt_tracer *t, int code, const std::string &msg) {
 
 extern "C" {
 
-const char *srt_version(void) { return "srt-hip 0.1 gfx950 parity (fp-contract=off, IEEE div/sqrt, detmath)"; }
+const char *srt_version(void) {
+#ifdef SRT_DEV_KNOBS
+	return "srt-hip 0.1 gfx950 parity (fp-contract=off, IEEE div/sqrt, detmath) [dev knobs]";
+#else
+	return "srt-hip 0.1 gfx950 parity (fp-contract=off, IEEE div/sqrt, detmath)";
+#endif
+}
 
 const char *srt_last_error(const srt_tracer *t) { return t ? t->err.c_str() : g_create_error.c_str(); }
 
@@ -462,6 +468,15 @@ int srt_partition_unpermute(const void *gathered, void *image, int height, int w
 	return SRT_OK;
 }
 
+// Development knobs (scheduling experiments and tests that force rare paths: SRT_WAVES_PER_CU, SRT_SCAN_PAIRS, SRT_JOB_CAP_SUBS,
+// SRT_POOL_BLOCKS, SRT_NO_SCAN_POOL) are read from the environment by -DSRT_DEV_KNOBS builds only (build.py build_dev():
+// lib/variants/dev/). The product library's scheduling does not depend on the caller's environment.
+#ifdef SRT_DEV_KNOBS
+static const char *dev_env(const char *name) { return getenv(name); }
+#else
+static const char *dev_env(const char *) { return nullptr; }
+#endif
+
 int srt_create(int width, int height, int device_index, srt_tracer **out) {
 	if (!out) return fail(nullptr, SRT_ERR_INVALID, "srt_create: out is NULL");
 	*out = nullptr;
@@ -479,6 +494,10 @@ int srt_create(int width, int height, int device_index, srt_tracer **out) {
 	t->height = height;
 	t->device = device_index;
 	t->owned_rows = height;
+	if (const char *env = getenv("SRT_RADIANCE_BUDGET_MB")) { // the one environment variable a deployment may want: read here, once
+		const long long mb = atoll(env);
+		if (mb > 0) t->radiance_budget_env = (size_t)mb << 20;
+	}
 	auto bail = [&](const char *what, hipError_t err) {
 		std::string m = std::string("srt_create: ") + what + ": " + hipGetErrorString(err);
 		srt_destroy(t);
@@ -948,10 +967,7 @@ int srt_trace(srt_tracer *t, const srt_render_data *options) {
 		size_t budget = free_b / 2; // leave half of what is free to the caller
 		const size_t cap = (size_t)96 << 30;
 		if (budget > cap) budget = cap;
-		if (const char *env = getenv("SRT_RADIANCE_BUDGET_MB")) {
-			const long long mb = atoll(env);
-			if (mb > 0) budget = (size_t)mb << 20;
-		}
+		if (t->radiance_budget_env) budget = t->radiance_budget_env; // SRT_RADIANCE_BUDGET_MB, read once by srt_create
 		t->radiance_budget = budget;
 	}
 	uint32_t batch = ns > 0 ? (uint32_t)ns : 0u;
@@ -972,7 +988,7 @@ int srt_trace(srt_tracer *t, const srt_render_data *options) {
 		if (t->scan_tris > 4096) {
 			const double per_sample = (double)pixels * (double)t->scan_tris;
 			double pairs = SRT_SCAN_PAIRS_PER_LAUNCH;
-			if (const char *env = getenv("SRT_SCAN_PAIRS")) // experiments only
+			if (const char *env = dev_env("SRT_SCAN_PAIRS"))
 				if (atof(env) > 0.0) pairs = atof(env);
 			const double cap = pairs / per_sample;
 			const uint32_t cap_u = cap < 1.0 ? 1u : (cap > 1e9 ? 0xffffffffu : (uint32_t)cap);
@@ -998,7 +1014,7 @@ int srt_trace(srt_tracer *t, const srt_render_data *options) {
 	p.radiance = t->radiance.ptr;
 	p.queue = t->counters.ptr + SRT_CTR_QUEUE;
 	int per_cu = srt_trace_resident_waves_per_cu(p, t->count_tris);
-	if (const char *env = getenv("SRT_WAVES_PER_CU")) { // experiments only
+	if (const char *env = dev_env("SRT_WAVES_PER_CU")) {
 		const int v = atoi(env);
 		if (v > 0 && v < per_cu) per_cu = v;
 	}
@@ -1006,12 +1022,35 @@ int srt_trace(srt_tracer *t, const srt_render_data *options) {
 	int slots = t->num_cus * per_cu;
 	if (slots > SRT_WAVE_CTR_SLOTS) slots = SRT_WAVE_CTR_SLOTS; // one counter line per persistent wave
 
-	if (t->num_models > 0 && (!t->bvh_active || srt_bvh_suspends()) && srt_scan_queue_in_hbm()) // one block per persistent wave, two sets (overlapping batches)
-		SRT_HIP(t, t->scan_queue.reserve(2 * SRT_SCAN_SET_FLOATS(slots))); // (per set: the pool's 84 MB and 46 KB per wave, 236 MB on 256 CUs)
-	uint32_t pool_blocks = t->scan_queue.ptr && !getenv("SRT_NO_SCAN_POOL") ? (uint32_t)SRT_POOL_BLOCKS : 0u;
-	if (const char *env = getenv("SRT_POOL_BLOCKS")) { // tests: a pool that overflows
+	// Array scan: one block of scan / park stacks per persistent wave the largest launch of this dispatch starts (46 KB each),
+	// the launch-end ray pool's records (84 MB), and a second set of both only when sample batches overlap: 320 MB for a
+	// one-launch frame on 256 CUs, 640 MB for an overlapped one. If the device cannot give that, the
+	// dispatch runs without the pool (every wave scans its own remainder: slower tails, same canvas) before it fails.
+	const bool wants_scan_queue = t->num_models > 0 && (!t->bvh_active || srt_bvh_suspends()) && srt_scan_queue_in_hbm();
+	const bool overlap_batches = SRT_OVERLAP_BATCHES && n_batches > 1;
+	size_t scan_waves = (size_t)slots;
+	{
+		const unsigned long long most_items = (unsigned long long)pixels * batch;
+		const unsigned long long need = (most_items + 63ull) / 64ull;
+		if (need < (unsigned long long)scan_waves) scan_waves = (size_t)(need ? need : 1ull);
+	}
+	uint32_t pool_blocks = wants_scan_queue && !dev_env("SRT_NO_SCAN_POOL") ? (uint32_t)SRT_POOL_BLOCKS : 0u;
+	if (const char *env = dev_env("SRT_POOL_BLOCKS")) { // tests: a pool that overflows
 		const int v = atoi(env);
 		if (v >= 0 && (uint32_t)v < pool_blocks) pool_blocks = (uint32_t)v;
+	}
+	if (wants_scan_queue) {
+		const size_t sets = overlap_batches ? 2 : 1;
+		hipError_t e = t->scan_queue.reserve(sets * SRT_SCAN_SET_FLOATS(scan_waves, pool_blocks != 0u));
+		if (e == hipErrorOutOfMemory && pool_blocks != 0u) {
+			(void)hipGetLastError();
+			pool_blocks = 0u;
+			e = t->scan_queue.reserve(sets * SRT_SCAN_SET_FLOATS(scan_waves, false));
+		}
+		if (e != hipSuccess) {
+			(void)hipGetLastError();
+			return fail(t, SRT_ERR_HIP, std::string("srt_trace: scan stacks: ") + hipGetErrorString(e));
+		}
 	}
 
 	ReduceParams rp;
@@ -1050,7 +1089,16 @@ int srt_trace(srt_tracer *t, const srt_render_data *options) {
 	const size_t radiance_stride = ((pixels * (size_t)batch * 3 + 4) + 3) & ~(size_t)3; // floats per buffer: a multiple of 4, so that the second buffer's float4 stores stay 16-byte aligned for any pixel count and batch size
 	if (overlap) {
 		for (int k = 0; k < 2; k++) {
-			if (!t->batch_stream[k]) SRT_HIP(t, hipStreamCreateWithFlags(&t->batch_stream[k], hipStreamNonBlocking));
+			if (!t->batch_stream[k]) {
+				// The two streams must not share a hardware queue, or the batches they carry run one after the other: the runtime
+				// deals its few queues out to streams as they are created, and in a process that holds other streams (bench.py:
+				// torch's, the headline handle's) both of these landed on one -- configs[4] 5.5 s instead of 4.3 s. Streams of
+				// different priority never share a queue, so the odd batches' stream is created one level above the even ones'.
+				int pr_low = 0, pr_high = 0;
+				(void)hipDeviceGetStreamPriorityRange(&pr_low, &pr_high); // (numerically lower = higher priority)
+				const int pr = (k == 1 && pr_high < pr_low) ? pr_low - 1 : pr_low;
+				SRT_HIP(t, hipStreamCreateWithPriority(&t->batch_stream[k], hipStreamNonBlocking, pr));
+			}
 			if (!t->ev_batch_traced[k]) SRT_HIP(t, hipEventCreateWithFlags(&t->ev_batch_traced[k], hipEventDisableTiming));
 			if (!t->ev_batch_reduced[k]) SRT_HIP(t, hipEventCreateWithFlags(&t->ev_batch_reduced[k], hipEventDisableTiming));
 		}
@@ -1065,7 +1113,7 @@ int srt_trace(srt_tracer *t, const srt_render_data *options) {
 		rp.radiance = p.radiance;
 		p.queue = t->counters.ptr + (par ? SRT_CTR_QUEUE2 : SRT_CTR_QUEUE);
 		p.wave_counters = t->wave_counters.ptr + (size_t)par * SRT_WAVE_CTR_SLOTS * SRT_WAVE_CTR_STRIDE;
-		p.scan_queue = t->scan_queue.ptr ? t->scan_queue.ptr + (size_t)par * SRT_SCAN_SET_FLOATS(slots) : nullptr;
+		p.scan_queue = wants_scan_queue ? t->scan_queue.ptr + (size_t)par * SRT_SCAN_SET_FLOATS(scan_waves, pool_blocks != 0u) : nullptr;
 		p.pool_blocks = pool_blocks;
 		if (overlap && b >= 2) SRT_HIP(t, hipStreamWaitEvent(ts, t->ev_batch_reduced[par], 0)); // batch b - 2 has been summed up
 		const uint32_t s0 = b * batch;
@@ -1107,7 +1155,7 @@ int srt_trace(srt_tracer *t, const srt_render_data *options) {
 			const unsigned long long most = t->bvh_active ? 16ull : 8ull;
 			cap_subs = cap_subs < 2ull ? 2ull : (cap_subs > most ? most : cap_subs);
 		}
-		if (const char *env = getenv("SRT_JOB_CAP_SUBS")) // experiments only
+		if (const char *env = dev_env("SRT_JOB_CAP_SUBS"))
 			if (atoi(env) > 0) cap_subs = (unsigned long long)atoi(env);
 		const unsigned long long job_cap = cap_subs * sub;
 		if (job > job_cap) job = job_cap;

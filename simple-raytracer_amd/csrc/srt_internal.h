@@ -67,6 +67,7 @@ struct srt_tracer {
 	DevBuf<float> radiance;  // 3 floats per (pixel, sample) of the current batch
 	DevBuf<float> running;   // float4 per pixel, carries the ordered sum across batches
 	size_t radiance_budget = 0; // bytes; 0 = pick from free HBM at first use
+	size_t radiance_budget_env = 0; // bytes from SRT_RADIANCE_BUDGET_MB as srt_create found it; 0 = not set
 	int num_cus = 0;
 	int last_waves_per_cu = 0, last_grid = 0;
 	std::vector<hipEvent_t> ev_k; // one pair per sample batch, around srt_trace_kernel alone (reduce excluded)

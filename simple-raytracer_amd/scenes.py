@@ -34,6 +34,27 @@ def synthetic_sky(w=SKY_W, h=SKY_H):
     return np.ascontiguousarray(out)
 
 
+def skybox_from_rgb8(img):
+    """Texel preparation of the reference's skybox upload for an 8-bit image (h, w, c) uint8 with c in 1..4, first row = top
+    of the picture: what stbi_loadf(..., 4) with stbi_set_flip_vertically_on_load(1) returns (src/tracer.cpp:42-46;
+    lib/stb_image.h:1857-1878): four channels, rows flipped, colour = (float)pow(byte / 255.0f, 2.2f) with the quotient in
+    float and pow in double, alpha = byte / 255.0f. Python mirror of host/skybox.hpp (srt_skybox_from_rgb8)."""
+    img = np.asarray(img, np.uint8)
+    if img.ndim == 2:
+        img = img[..., None]
+    h, w, c = img.shape
+    q = np.arange(256, dtype=np.float32) / np.float32(255.0)
+    lut = np.power(q.astype(np.float64), np.float64(np.float32(2.2))).astype(np.float32)
+    out = np.empty((h, w, 4), np.float32)
+    src = img[::-1]
+    grey = c < 3
+    out[..., 0] = lut[src[..., 0]]
+    out[..., 1] = lut[src[..., 0 if grey else 1]]
+    out[..., 2] = lut[src[..., 0 if grey else 2]]
+    out[..., 3] = q[src[..., c - 1]] if c in (2, 4) else np.float32(1.0)
+    return np.ascontiguousarray(out)
+
+
 def _stack(items, dtype):
     a = np.zeros(len(items), dtype)
     for i, it in enumerate(items):

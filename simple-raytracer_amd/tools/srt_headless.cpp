@@ -5,7 +5,10 @@
 //
 //   srt_headless [--scene spheres|meshes|empty] [--obj f.obj]... [--stl f.stl]...
 //                [--width W --height H --spp S --bounces B --frames N --time T]
-//                [--out frame.ppm] [--dump prefix] [--parse-only] [--bvh] [--gpus N] [--pipelined]
+//                [--out frame.ppm] [--dump prefix] [--parse-only] [--bvh] [--gpus N] [--pipelined] [--skybox sky.ppm]
+//
+// --skybox sky.ppm: an 8-bit binary PPM (P6) as the sky, prepared the way the reference prepares assets/skybox.png
+//                   (host/skybox.hpp: four channels, rows flipped, pow(byte / 255, 2.2)); default: the synthetic sky.
 //
 // --dump prefix writes prefix.{shapes,tris,mats,rd,sd,canvas,argb}.bin (raw records).
 // --parse-only skips everything that needs a GPU (loaders + scene construction only).
@@ -19,7 +22,33 @@
 #include <vector>
 
 #include "../host/parser.hpp"
+#include "../host/skybox.hpp"
 #include "../host/tracer.hpp"
+
+// binary PPM (P6, maxval 255; comments allowed in the header) -> RGB bytes, first row = top of the picture
+static bool load_ppm(const std::string &path, std::vector<uint8_t> &rgb, int &w, int &h) {
+	std::ifstream f(path, std::ios::binary);
+	if (!f) return false;
+	std::string magic;
+	f >> magic;
+	if (magic != "P6") return false;
+	int vals[3], got = 0;
+	while (got < 3 && f) {
+		f >> std::ws;
+		if (f.peek() == '#') {
+			std::string line;
+			std::getline(f, line);
+			continue;
+		}
+		f >> vals[got++];
+	}
+	if (got < 3 || vals[0] <= 0 || vals[1] <= 0 || vals[2] != 255) return false;
+	f.get(); // the single whitespace byte behind maxval
+	w = vals[0], h = vals[1];
+	rgb.resize((size_t)w * h * 3);
+	f.read(reinterpret_cast<char *>(rgb.data()), (std::streamsize)rgb.size());
+	return (size_t)f.gcount() == rgb.size();
+}
 
 // same integer formula as simple-raytracer_amd/scenes.py synthetic_sky()
 static std::vector<float> synthetic_sky(int w, int h) {
@@ -65,7 +94,7 @@ static void dump(const std::string &path, const T *data, size_t count) {
 }
 
 int main(int argc, char **argv) {
-	std::string scene = "spheres", out, dump_prefix;
+	std::string scene = "spheres", out, dump_prefix, skybox_path;
 	std::vector<std::string> objs, stls;
 	int width = 256, height = 256, spp = 16, bounces = 10, frames = 1;
 	unsigned time_seed = 12345;
@@ -95,9 +124,10 @@ int main(int argc, char **argv) {
 		else if (a == "--bvh") bvh = true;
 		else if (a == "--gpus") gpus = std::atoi(next());
 		else if (a == "--pipelined") pipelined = true;
+		else if (a == "--skybox") skybox_path = next();
 		else {
 			std::cerr << "usage: srt_headless [--scene spheres|meshes|empty] [--obj f]... [--stl f]... [--width W --height H --spp S "
-			             "--bounces B --frames N --time T] [--out f.ppm] [--dump prefix] [--parse-only] [--bvh] [--gpus N] [--pipelined]\n";
+			             "--bounces B --frames N --time T] [--out f.ppm] [--dump prefix] [--parse-only] [--bvh] [--gpus N] [--pipelined] [--skybox sky.ppm]\n";
 			return 2;
 		}
 	}
@@ -173,9 +203,21 @@ int main(int argc, char **argv) {
 	tracer.scene_data.sun_color = color::from_hex(0xffffd3);
 	tracer.scene_data.sun_intensity = 1.0f;
 	tracer.scene_data.sun_direction = VEC3TOCL(glm::normalize(glm::vec3(1.0f, -1.0f, 0.0f)));
-	const int sky_w = 2048, sky_h = 1024;
-	std::vector<float> sky = synthetic_sky(sky_w, sky_h);
+	int sky_w = 2048, sky_h = 1024;
+	std::vector<float> sky;
+	if (!skybox_path.empty()) {
+		std::vector<uint8_t> rgb;
+		if (!load_ppm(skybox_path, rgb, sky_w, sky_h)) {
+			std::cerr << "cannot read " << skybox_path << " (binary PPM, P6, maxval 255)\n";
+			return 3;
+		}
+		sky.resize((size_t)sky_w * sky_h * 4);
+		srt_skybox_from_rgb8(rgb.data(), sky_w, sky_h, 3, sky.data()); // as stbi_loadf + flip (src/tracer.cpp:42-46)
+	} else {
+		sky = synthetic_sky(sky_w, sky_h);
+	}
 	tracer.set_skybox(sky.data(), sky_w, sky_h);
+	if (!dump_prefix.empty()) dump(dump_prefix + ".sky.bin", sky.data(), sky.size());
 
 	std::vector<uint8_t> pixels((size_t)width * height * 4);
 

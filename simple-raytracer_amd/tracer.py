@@ -11,6 +11,7 @@ from pathlib import Path
 
 import numpy as np
 
+from . import build as B
 from . import records as R
 
 PKG = Path(__file__).resolve().parent
@@ -110,7 +111,28 @@ def load_library():
         return _lib
     if not LIB_PATH.exists():
         raise SrtError(f"{LIB_PATH} not built: run `python __graft_entry__.py` / simple-raytracer_amd/build.py (needs hipcc)")
-    lib = C.CDLL(str(LIB_PATH))
+    _lib = _bind(C.CDLL(str(LIB_PATH)))
+    return _lib
+
+
+_variants = {}
+
+
+def load_dev_library():
+    """The -DSRT_DEV_KNOBS build (lib/variants/dev/, build.py build_dev()): the same library, which additionally reads the
+    development knobs SRT_WAVES_PER_CU / SRT_SCAN_PAIRS / SRT_JOB_CAP_SUBS / SRT_POOL_BLOCKS / SRT_NO_SCAN_POOL from the
+    environment. Tests that force rare paths pass it to Tracer(lib=...); the product library ignores those variables."""
+    path = B.DEV_LIB
+    if str(path) not in _variants:
+        if not path.exists():
+            raise SrtError(f"{path} not built: simple_raytracer_amd.build.build_dev()")
+        lib = _bind(C.CDLL(str(path)))
+        assert b"dev knobs" in lib.srt_version(), lib.srt_version()
+        _variants[str(path)] = lib
+    return _variants[str(path)]
+
+
+def _bind(lib):
     vp, i, sz = C.c_void_p, C.c_int, C.c_size_t
     lib.srt_create.argtypes = [i, i, i, C.POINTER(vp)]
     lib.srt_destroy.argtypes = [vp]
@@ -177,7 +199,6 @@ def load_library():
         lib.srt_group_get_counters.argtypes = [vp, C.POINTER(Counters)]
         lib.srt_render_pipelined.argtypes = [vp, vp, C.c_uint32, vp, C.POINTER(C.c_longlong)]
         lib.srt_pipeline_flush.argtypes = [vp, vp, C.POINTER(C.c_longlong)]
-    _lib = lib
     return lib
 
 
@@ -189,8 +210,8 @@ class Tracer:
     """Mirror of the reference's `class Tracer`. Field and method names are the
     reference's; records are numpy scalars of records.RENDER_DATA / SCENE_DATA."""
 
-    def __init__(self, width, height, device=0):
-        self.lib = load_library()
+    def __init__(self, width, height, device=0, lib=None):
+        self.lib = lib if lib is not None else load_library()
         self._h = C.c_void_p()
         rc = self.lib.srt_create(width, height, device, C.byref(self._h))
         if rc:

@@ -21,9 +21,9 @@ def T():
     return tracer
 
 
-def make_tracer(T, g, sky, rd=None):
+def make_tracer(T, g, sky, rd=None, lib=None):
     rd = g["rd"] if rd is None else rd
-    t = T.Tracer(int(rd["width"]), int(rd["height"]))
+    t = T.Tracer(int(rd["width"]), int(rd["height"]), lib=lib)
     t.set_skybox(sky)
     t.options = rd.copy()
     t.scene_data = g["sd"].copy()
@@ -92,11 +92,12 @@ def test_scan_pool_sizes_are_invisible(T, sky, oracle, monkeypatch):
     rd = R.render_data(160, 90, 6, 10, camera_to_world=S.default_camera(), time=777)
     g = dict(shapes=shapes, tris=tris, mats=mats, rd=rd, sd=R.scene_data(len(shapes)))
     want = oracle.render(rd, g["sd"], shapes, tris, mats, sky)
+    dev = T.load_dev_library()  # the knobs below exist in the -DSRT_DEV_KNOBS build only
     for env, val in ((None, None), ("SRT_POOL_BLOCKS", "1"), ("SRT_POOL_BLOCKS", "7"), ("SRT_NO_SCAN_POOL", "1")):
         if env:
             monkeypatch.setenv(env, val)
         for budget in (0, 160 * 90 * 12 * 2):
-            t = make_tracer(T, g, sky)
+            t = make_tracer(T, g, sky, lib=dev)
             if budget:
                 t.set_radiance_budget(budget)  # three launches of two samples
             t.trace()
@@ -118,7 +119,7 @@ def test_chunk_sizes_are_invisible(T, sky, oracle, monkeypatch, accel):
     for cap in (None, "1", "3", "16"):
         if cap:
             monkeypatch.setenv("SRT_JOB_CAP_SUBS", cap)
-        t = T.Tracer(96, 54)
+        t = T.Tracer(96, 54, lib=T.load_dev_library())
         t.set_skybox(sky)
         if accel:
             t.set_acceleration(T.ACCEL_BVH)

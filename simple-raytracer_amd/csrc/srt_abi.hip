@@ -607,8 +607,25 @@ int srt_update_scene(srt_tracer *t, const srt_shape *shapes, size_t n_shapes, co
 	}
 }
 
-static int update_scene_impl(srt_tracer *t, const srt_shape *shapes, size_t n_shapes, const srt_triangle *triangles, size_t n_triangles,
-                             const srt_material *materials, size_t n_materials, const srt_scene_data *scene) {
+// Everything a device needs of a scene, made on the host ONCE per srt_update_scene / srt_group_update_scene: shape blocks and group
+// headers, winner records, world-triangle offsets, the hierarchy in its device form, the device material table (bernoulli()
+// thresholds, Schlick constants). A group of N devices prepares one of these and uploads it N times (round 4; before, the whole
+// host pass -- 18 ms of BVH build for 10^5 triangles -- ran once per device, in turn).
+struct ScenePrep {
+	std::vector<BlockGroup> groups;
+	std::vector<float> data;
+	std::vector<WinnerRec> winners;
+	std::vector<uint32_t> offs, bvh_blocks, bvh_order, bvh_dest;
+	std::vector<srt_material> dev_mats;
+	uint64_t total_wtris = 0, max_tris = 0;
+	int num_models = 0;
+	bool use_bvh = false, unit_materials = false, all_materials_ok = true;
+	uint64_t bvh_info[7] = {0, 0, 0, 0, 0, 0, 0};
+};
+
+// host pass; `t` supplies the acceleration mode and owns the hierarchy cache (a group: its first member)
+static int prepare_scene(srt_tracer *t, ScenePrep &sp, const srt_shape *shapes, size_t n_shapes, const srt_triangle *triangles, size_t n_triangles,
+                         const srt_material *materials, size_t n_materials, const srt_scene_data *scene) {
 	if (!t) return SRT_ERR_INVALID;
 	if (!scene) return fail(t, SRT_ERR_INVALID, "srt_update_scene: scene is NULL");
 	if ((n_shapes && !shapes) || (n_triangles && !triangles) || (n_materials && !materials))
@@ -619,14 +636,16 @@ static int update_scene_impl(srt_tracer *t, const srt_shape *shapes, size_t n_sh
 	// per-shape winner records and world-triangle offsets. The reference would read out of
 	// bounds for a bad triangle range or material index; we refuse instead.
 	std::vector<ShapeRun> runs;
-	std::vector<float> data; // packed, every run starts on a 16-dword boundary
-	std::vector<WinnerRec> winners(n_shapes ? n_shapes : 1);
-	std::vector<uint32_t> offs(n_shapes ? n_shapes : 1, 0u);
-	uint64_t total_wtris = 0, max_tris = 0;
-	int num_models = 0;
-	const bool use_bvh = t->accel_mode == SRT_ACCEL_BVH;
-	std::vector<uint32_t> bvh_blocks; // 32 dwords each (device_types.h)
-	std::vector<uint32_t> bvh_order, bvh_dest;
+	std::vector<float> &data = sp.data; // packed, every run starts on a 16-dword boundary
+	std::vector<WinnerRec> &winners = sp.winners;
+	winners.assign(n_shapes ? n_shapes : 1, WinnerRec());
+	std::vector<uint32_t> &offs = sp.offs;
+	offs.assign(n_shapes ? n_shapes : 1, 0u);
+	uint64_t &total_wtris = sp.total_wtris, &max_tris = sp.max_tris;
+	int &num_models = sp.num_models;
+	const bool use_bvh = sp.use_bvh = t->accel_mode == SRT_ACCEL_BVH;
+	std::vector<uint32_t> &bvh_blocks = sp.bvh_blocks; // 32 dwords each (device_types.h)
+	std::vector<uint32_t> &bvh_order = sp.bvh_order, &bvh_dest = sp.bvh_dest;
 	uint64_t bvh_leaves = 0, bvh_depth = 0, bvh_reused = 0, bvh_refitted = 0, bvh_canonical_nodes = 0;
 	std::deque<BvhCacheEntry> fresh;                 // hierarchies built by this call (deque: growth keeps references valid)
 	std::vector<std::pair<bool, size_t>> plan;       // per model with triangles: {from the cache?, index there / in fresh}
@@ -776,7 +795,8 @@ static int update_scene_impl(srt_tracer *t, const srt_shape *shapes, size_t n_sh
 	}
 	pad_run();
 	// group headers: three blocks each (device_types.h BlockGroup); the data of a last, partial group is zero-filled
-	std::vector<BlockGroup> groups((runs.size() + 2) / 3);
+	std::vector<BlockGroup> &groups = sp.groups;
+	groups.assign((runs.size() + 2) / 3, BlockGroup());
 	uint32_t n_big = 0; // big model number k waits in scan stack k & 1 (kernels.hip)
 	for (size_t b = 0; b < runs.size(); b++) {
 		BlockGroup &g = groups[b / 3];
@@ -789,6 +809,70 @@ static int update_scene_impl(srt_tracer *t, const srt_shape *shapes, size_t n_sh
 	const uint64_t build_us =
 	    (uint64_t)std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - build_t0).count();
 
+	// Device-side material table = the caller's records with three per-material constants
+	// parked in padding floats, so the glass branch does no division at all:
+	//   _pad[0] (offset 24) = 1.0f / refraction_index                      (render.cl:442, front face)
+	//   _pad[1] (offset 28) = Schlick r0 for mu = 1/refraction_index       (render.cl:174-175, fp64 then float)
+	//   color._pad (offset 44) = Schlick r0 for mu = refraction_index      (back face)
+	// Same IEEE operations the kernel would run per hit, hence the same bits.
+	std::vector<srt_material> &dev_mats = sp.dev_mats;
+	dev_mats.assign(materials, materials + n_materials);
+	auto schlick_r0 = [](float mu) {
+		float r0 = (float)((1.0 - (double)mu) / (1.0 + (double)mu));
+		return r0 * r0;
+	};
+	// bernoulli() thresholds (kernels.hip): T(p) = how many of the generator's 2^32 outputs r give p > (float)r * 2^-32 -- a prefix,
+	// the conversion is monotone. When every probability of the scene has T < 2^32 (p <= 1 does) the device table carries the
+	// thresholds' bits in place of metallic / specular / transmittance.
+	auto threshold = [](float pr) -> uint64_t {
+		uint64_t lo = 0, hi = (uint64_t)1 << 32; // first r in [lo, hi] for which !(pr > u(r)); hi = 2^32: none
+		while (lo < hi) {
+			const uint64_t mid = (lo + hi) >> 1;
+			const float u = (float)(uint32_t)mid * 2.3283064365386963e-10f;
+			if (pr > u) lo = mid + 1;
+			else hi = mid;
+		}
+		return lo;
+	};
+	bool unit_materials = true;
+	for (const auto &m : dev_mats)
+		if (threshold(m.metallic) >> 32 || threshold(m.specular) >> 32 || threshold(m.transmittance) >> 32) unit_materials = false;
+	sp.unit_materials = unit_materials;
+	for (auto &m : dev_mats) {
+		if (unit_materials) {
+			const uint32_t tm = (uint32_t)threshold(m.metallic), ts = (uint32_t)threshold(m.specular), tt = (uint32_t)threshold(m.transmittance);
+			memcpy(&m.metallic, &tm, 4), memcpy(&m.specular, &ts, 4), memcpy(&m.transmittance, &tt, 4);
+		}
+		const float inv_ior = 1.0f / m.refraction_index;
+		m._pad[0] = inv_ior;
+		m._pad[1] = schlick_r0(inv_ior);
+		m.color._pad = schlick_r0(m.refraction_index);
+	}
+	sp.bvh_info[0] = bvh_canonical_nodes, sp.bvh_info[1] = bvh_leaves, sp.bvh_info[2] = bvh_depth, sp.bvh_info[3] = use_bvh ? build_us : 0;
+	sp.bvh_info[4] = use_bvh ? plan.size() - bvh_reused - bvh_refitted : 0, sp.bvh_info[5] = bvh_reused, sp.bvh_info[6] = bvh_refitted;
+	if (use_bvh) {
+		std::vector<BvhCacheEntry> next_cache;
+		next_cache.reserve(plan.size());
+		for (const auto &pl : plan) next_cache.push_back(std::move(pl.first ? t->bvh_cache->entries[pl.second] : fresh[pl.second]));
+		t->bvh_cache->entries = std::move(next_cache);
+	}
+	sp.all_materials_ok = true;
+	for (size_t i = 0; i < n_shapes; i++)
+		if (shapes[i].material < 0) sp.all_materials_ok = false;
+	return SRT_OK;
+}
+
+// device pass, first half: wait for the handle's previous launches, (re)allocate, enqueue every upload and the pre-pass on its stream
+static int upload_scene_begin(srt_tracer *t, const ScenePrep &sp, const srt_shape *shapes, size_t n_shapes, const srt_triangle *triangles,
+                              size_t n_triangles, size_t n_materials) {
+	const std::vector<BlockGroup> &groups = sp.groups;
+	const std::vector<float> &data = sp.data;
+	const std::vector<WinnerRec> &winners = sp.winners;
+	const std::vector<uint32_t> &offs = sp.offs, &bvh_blocks = sp.bvh_blocks, &bvh_order = sp.bvh_order, &bvh_dest = sp.bvh_dest;
+	const std::vector<srt_material> &dev_mats = sp.dev_mats;
+	const bool use_bvh = sp.use_bvh;
+	const uint64_t total_wtris = sp.total_wtris, max_tris = sp.max_tris;
+	const int num_models = sp.num_models;
 	SRT_HIP(t, hipSetDevice(t->device));
 	SRT_HIP(t, hipStreamSynchronize(t->stream)); // previous launches may still read the old scene
 	SRT_HIP(t, t->shapes.reserve(n_shapes));
@@ -821,44 +905,6 @@ static int update_scene_impl(srt_tracer *t, const srt_shape *shapes, size_t n_sh
 	SRT_HIP(t, hipMemcpyAsync(t->run_data.ptr, data.data(), data.size() * sizeof(float), hipMemcpyHostToDevice, t->stream));
 	if (n_triangles)
 		SRT_HIP(t, hipMemcpyAsync(t->triangles.ptr, triangles, n_triangles * sizeof(srt_triangle), hipMemcpyHostToDevice, t->stream));
-	// Device-side material table = the caller's records with three per-material constants
-	// parked in padding floats, so the glass branch does no division at all:
-	//   _pad[0] (offset 24) = 1.0f / refraction_index                      (render.cl:442, front face)
-	//   _pad[1] (offset 28) = Schlick r0 for mu = 1/refraction_index       (render.cl:174-175, fp64 then float)
-	//   color._pad (offset 44) = Schlick r0 for mu = refraction_index      (back face)
-	// Same IEEE operations the kernel would run per hit, hence the same bits.
-	std::vector<srt_material> dev_mats(materials, materials + n_materials);
-	auto schlick_r0 = [](float mu) {
-		float r0 = (float)((1.0 - (double)mu) / (1.0 + (double)mu));
-		return r0 * r0;
-	};
-	// bernoulli() thresholds (kernels.hip): T(p) = how many of the generator's 2^32 outputs r give p > (float)r * 2^-32 -- a prefix,
-	// the conversion is monotone. When every probability of the scene has T < 2^32 (p <= 1 does) the device table carries the
-	// thresholds' bits in place of metallic / specular / transmittance.
-	auto threshold = [](float pr) -> uint64_t {
-		uint64_t lo = 0, hi = (uint64_t)1 << 32; // first r in [lo, hi] for which !(pr > u(r)); hi = 2^32: none
-		while (lo < hi) {
-			const uint64_t mid = (lo + hi) >> 1;
-			const float u = (float)(uint32_t)mid * 2.3283064365386963e-10f;
-			if (pr > u) lo = mid + 1;
-			else hi = mid;
-		}
-		return lo;
-	};
-	bool unit_materials = true;
-	for (const auto &m : dev_mats)
-		if (threshold(m.metallic) >> 32 || threshold(m.specular) >> 32 || threshold(m.transmittance) >> 32) unit_materials = false;
-	t->unit_materials = unit_materials;
-	for (auto &m : dev_mats) {
-		if (unit_materials) {
-			const uint32_t tm = (uint32_t)threshold(m.metallic), ts = (uint32_t)threshold(m.specular), tt = (uint32_t)threshold(m.transmittance);
-			memcpy(&m.metallic, &tm, 4), memcpy(&m.specular, &ts, 4), memcpy(&m.transmittance, &tt, 4);
-		}
-		const float inv_ior = 1.0f / m.refraction_index;
-		m._pad[0] = inv_ior;
-		m._pad[1] = schlick_r0(inv_ior);
-		m.color._pad = schlick_r0(m.refraction_index);
-	}
 	if (n_materials)
 		SRT_HIP(t, hipMemcpyAsync(t->materials.ptr, dev_mats.data(), n_materials * sizeof(srt_material), hipMemcpyHostToDevice, t->stream));
 
@@ -880,28 +926,70 @@ static int update_scene_impl(srt_tracer *t, const srt_shape *shapes, size_t n_sh
 		}
 		SRT_HIP(t, hipGetLastError());
 	}
-	SRT_HIP(t, hipStreamSynchronize(t->stream)); // host arrays are free again on return
+	return SRT_OK;
+}
 
+// device pass, second half: the uploads have arrived (the host arrays are free again), the handle describes the new scene
+static int upload_scene_end(srt_tracer *t, const ScenePrep &sp, size_t n_shapes, size_t n_materials, const srt_scene_data *scene) {
+	SRT_HIP(t, hipSetDevice(t->device));
+	SRT_HIP(t, hipStreamSynchronize(t->stream));
 	t->sd = *scene;
 	t->sd.num_shapes = (int32_t)n_shapes; // src/tracer.cpp:94
-	t->num_models = num_models;
-	t->scan_tris = use_bvh ? 0 : total_wtris;
-	t->bvh_active = use_bvh && num_models > 0;
-	t->bvh_info[0] = bvh_canonical_nodes, t->bvh_info[1] = bvh_leaves, t->bvh_info[2] = bvh_depth, t->bvh_info[3] = use_bvh ? build_us : 0;
-	t->bvh_info[4] = use_bvh ? plan.size() - bvh_reused - bvh_refitted : 0, t->bvh_info[5] = bvh_reused, t->bvh_info[6] = bvh_refitted;
-	if (use_bvh) {
-		std::vector<BvhCacheEntry> next_cache;
-		next_cache.reserve(plan.size());
-		for (const auto &pl : plan) next_cache.push_back(std::move(pl.first ? t->bvh_cache->entries[pl.second] : fresh[pl.second]));
-		t->bvh_cache->entries = std::move(next_cache);
-	}
-	t->all_materials_ok = true;
-	for (size_t i = 0; i < n_shapes; i++)
-		if (shapes[i].material < 0) t->all_materials_ok = false;
-	t->num_runs = (int)groups.size();
+	t->num_models = sp.num_models;
+	t->scan_tris = sp.use_bvh ? 0 : sp.total_wtris;
+	t->bvh_active = sp.use_bvh && sp.num_models > 0;
+	for (int k = 0; k < 7; k++) t->bvh_info[k] = sp.bvh_info[k];
+	t->all_materials_ok = sp.all_materials_ok;
+	t->unit_materials = sp.unit_materials;
+	t->num_runs = (int)sp.groups.size();
 	t->num_materials = n_materials;
 	t->scene_set = true;
 	return SRT_OK;
+}
+
+
+static int update_scene_impl(srt_tracer *t, const srt_shape *shapes, size_t n_shapes, const srt_triangle *triangles, size_t n_triangles,
+                             const srt_material *materials, size_t n_materials, const srt_scene_data *scene) {
+	if (!t) return SRT_ERR_INVALID;
+	ScenePrep sp;
+	int rc = prepare_scene(t, sp, shapes, n_shapes, triangles, n_triangles, materials, n_materials, scene);
+	if (rc == SRT_OK) rc = upload_scene_begin(t, sp, shapes, n_shapes, triangles, n_triangles, n_materials);
+	if (rc == SRT_OK) rc = upload_scene_end(t, sp, n_shapes, n_materials, scene);
+	return rc;
+}
+
+// One scene for N handles (srt_group_update_scene): prepared once with members[0]'s acceleration mode and hierarchy cache, uploaded to
+// all of them -- every device's copies and pre-pass are enqueued before the first is waited for. On an error the members that
+// were not reached keep their previous scene.
+int srt_update_scene_many(srt_tracer *const *members, size_t n_members, const srt_shape *shapes, size_t n_shapes, const srt_triangle *triangles,
+                          size_t n_triangles, const srt_material *materials, size_t n_materials, const srt_scene_data *scene, size_t *failed_member) {
+	if (failed_member) *failed_member = 0;
+	if (!members || n_members == 0 || !members[0]) return SRT_ERR_INVALID;
+	try {
+		ScenePrep sp;
+		int rc = prepare_scene(members[0], sp, shapes, n_shapes, triangles, n_triangles, materials, n_materials, scene);
+		if (rc != SRT_OK) return rc;
+		size_t begun = 0;
+		for (; begun < n_members && rc == SRT_OK; begun++) {
+			if (failed_member) *failed_member = begun;
+			members[begun]->accel_mode = members[0]->accel_mode; // (the prepared scene is in this form)
+			rc = upload_scene_begin(members[begun], sp, shapes, n_shapes, triangles, n_triangles, n_materials);
+		}
+		if (rc != SRT_OK) { // what was enqueued on the members before the failing one still reads the host arrays: let it finish
+			for (size_t i = 0; i + 1 < begun; i++) (void)upload_scene_end(members[i], sp, n_shapes, n_materials, scene);
+			return rc;
+		}
+		for (size_t i = 0; i < n_members; i++) {
+			if (failed_member) *failed_member = i;
+			const int r = upload_scene_end(members[i], sp, n_shapes, n_materials, scene);
+			if (r != SRT_OK && rc == SRT_OK) rc = r;
+		}
+		return rc;
+	} catch (const std::bad_alloc &) {
+		return fail(members[0], SRT_ERR_INVALID, "out of host memory");
+	} catch (...) {
+		return SRT_ERR_INVALID;
+	}
 }
 
 int srt_clear_canvas(srt_tracer *t) {

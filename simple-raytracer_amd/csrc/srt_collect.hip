@@ -257,6 +257,13 @@ int srt_read_gathered(srt_tracer *t, float *canvas_out, uint8_t *argb_out) {
 struct srt_group {
 	std::vector<srt_tracer *> t;
 	int width = 0, height = 0, rpb = 8;
+	// The device list names a device more than once ("virtual devices": N members on fewer GPUs, down to one). RCCL refuses such a
+	// list, and there is no link to cross: the collection is then a device-to-device copy of every member's packed canvas into its
+	// slot of the root's buffer, enqueued on the member's own stream where ncclGather would be, and the root's stream waits for all
+	// of them before it unpermutes. Partition, packed layout, unpermute, resolve and every srt_group_* call are the real ones --
+	// what a one-GPU box can run of the N > 1 path (tests/test_gpu_collect.py).
+	bool loopback = false;
+	std::vector<hipEvent_t> copied; // loopback: member i's canvas has arrived in the root's buffer
 	std::string err;
 };
 
@@ -271,6 +278,8 @@ extern "C" {
 
 void srt_group_destroy(srt_group *g) {
 	if (!g) return;
+	for (hipEvent_t e : g->copied)
+		if (e) (void)hipEventDestroy(e);
 	for (srt_tracer *t : g->t) {
 		if (t && t->collect && t->collect->comm && rccl().lib) {
 			(void)hipSetDevice(t->device);
@@ -293,7 +302,17 @@ int srt_group_create(int width, int height, int n_devices, const int *devices, i
 	if (!g) return fail(nullptr, SRT_ERR_INVALID, "out of host memory");
 	g->width = width, g->height = height, g->rpb = rows_per_block;
 	std::vector<int> devs(n_devices);
-	for (int i = 0; i < n_devices; i++) devs[i] = devices ? devices[i] : i;
+	int ndev = 0;
+	if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+		(void)hipGetLastError();
+		delete g;
+		return fail(nullptr, SRT_ERR_HIP, "srt_group_create: no HIP device");
+	}
+	// no list: devices 0 .. n-1; more members than the node has devices: they wrap around (virtual devices, see srt_group::loopback)
+	for (int i = 0; i < n_devices; i++) devs[i] = devices ? devices[i] : i % ndev;
+	for (int i = 0; i < n_devices && !g->loopback; i++)
+		for (int k = 0; k < i; k++)
+			if (devs[k] == devs[i]) g->loopback = true;
 	for (int i = 0; i < n_devices; i++) {
 		srt_tracer *t = nullptr;
 		int rc = srt_create(width, height, devs[i], &t);
@@ -305,6 +324,21 @@ int srt_group_create(int width, int height, int n_devices, const int *devices, i
 			return fail(nullptr, rc, msg);
 		}
 		g->t.push_back(t);
+	}
+	if (g->loopback) {
+		for (int i = 0; i < n_devices; i++) {
+			SrtCollect *c = collect_of(g->t[i]);
+			hipEvent_t ev = nullptr;
+			if (!c || hipSetDevice(devs[i]) != hipSuccess || hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) {
+				(void)hipGetLastError();
+				srt_group_destroy(g);
+				return fail(nullptr, SRT_ERR_HIP, "srt_group_create: loopback set-up");
+			}
+			g->copied.push_back(ev);
+			c->comm_rank = i, c->comm_world = n_devices;
+		}
+		*out = g;
+		return SRT_OK;
 	}
 	if (!rccl_load()) {
 		srt_group_destroy(g);
@@ -361,7 +395,10 @@ int srt_group_set_acceleration(srt_group *g, int mode) {
 int srt_group_update_scene(srt_group *g, const srt_shape *shapes, size_t n_shapes, const srt_triangle *triangles, size_t n_triangles,
                            const srt_material *materials, size_t n_materials, const srt_scene_data *scene) {
 	if (!g) return SRT_ERR_INVALID;
-	SRT_EACH(g, srt_update_scene(t_, shapes, n_shapes, triangles, n_triangles, materials, n_materials, scene)); // the scene is replicated
+	// the scene is replicated: prepared on the host once (hierarchy build, shape blocks, thresholds), uploaded to every member
+	size_t who = 0;
+	const int rc = srt_update_scene_many(g->t.data(), g->t.size(), shapes, n_shapes, triangles, n_triangles, materials, n_materials, scene, &who);
+	if (rc != SRT_OK) return gfail(g, rc, srt_last_error(g->t[who < g->t.size() ? who : 0]));
 	return SRT_OK;
 }
 
@@ -382,6 +419,21 @@ int srt_group_trace_and_gather(srt_group *g, const srt_render_data *options) {
 	SrtCollect *rc = root->collect;
 	if (hipSetDevice(root->device) != hipSuccess || rc->gathered.reserve(count * (size_t)world) != hipSuccess)
 		return gfail(g, SRT_ERR_HIP, "srt_group: gather buffer on the root device");
+	if (g->loopback) {
+		for (int i = 0; i < world; i++) {
+			srt_tracer *t = g->t[i];
+			if (hipSetDevice(t->device) != hipSuccess ||
+			    hipMemcpyAsync(rc->gathered.ptr + (size_t)i * count, t->canvas, count * sizeof(float), hipMemcpyDeviceToDevice, t->stream) != hipSuccess ||
+			    hipEventRecord(g->copied[i], t->stream) != hipSuccess)
+				return gfail(g, SRT_ERR_HIP, "srt_group: loopback copy of a member's canvas");
+		}
+		(void)hipSetDevice(root->device);
+		for (int i = 1; i < world; i++)
+			if (hipStreamWaitEvent(root->stream, g->copied[i], 0) != hipSuccess) return gfail(g, SRT_ERR_HIP, "srt_group: loopback wait");
+		const int u = unpermute_on_root(root, rc);
+		if (u != SRT_OK) return gfail(g, u, srt_last_error(root));
+		return SRT_OK;
+	}
 	int r = rccl().GroupStart();
 	for (int i = 0; i < world && r == kNcclSuccess; i++) {
 		srt_tracer *t = g->t[i];

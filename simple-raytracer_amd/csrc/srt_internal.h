@@ -104,5 +104,9 @@ static inline int fail(srt_tracer *t, int code, const std::string &msg) { return
 
 
 void srt_collect_release(srt_tracer *t);
+/* one scene for several handles: the host pass once (members[0]'s acceleration mode and hierarchy cache), the uploads of all
+ * members enqueued before the first is waited for (srt_abi.hip; srt_group_update_scene). *failed_member = the member an error came from */
+extern "C" int srt_update_scene_many(srt_tracer *const *members, size_t n_members, const srt_shape *shapes, size_t n_shapes, const srt_triangle *triangles,
+                          size_t n_triangles, const srt_material *materials, size_t n_materials, const srt_scene_data *scene, size_t *failed_member);
 
 #endif

@@ -1,9 +1,9 @@
 """GPU (MI355X): what happens to a frame after the trace kernel beyond one blocking device (csrc/srt_collect.hip):
 the in-library RCCL gather (one process per GPU: srt_comm_* / srt_gather; one process, several GPUs: srt_group_*)
-and the two-deep frame pipeline. One GPU is what the test box has, so the collective runs with world = 1 -- the
-communicator, the ncclGather call, the unpermute kernel and the resolve of the gathered image are the real ones; the
-N > 1 layout is covered bit for bit by the virtual-tile and gloo tests (test_gpu_parity.py, test_partition_gloo.py)
-and by the unpermute check below, which feeds the kernel a hand-packed 3-rank buffer."""
+and the two-deep frame pipeline. One GPU is what the test box has: RCCL itself runs with world = 1 (the communicator, the
+ncclGather call, the unpermute kernel and the resolve of the gathered image are the real ones), and the N > 1 code of
+srt_group_* runs on VIRTUAL devices -- N members on the one GPU, collected by device-to-device copies where ncclGather
+would be (round 4). No run on more than one GPU exists yet."""
 import numpy as np
 import pytest
 
@@ -42,6 +42,78 @@ def test_group_of_one_device_renders_the_golden_frames(T, sky):
         c = grp.counters()
         assert c["paths"] == w * h * int(g["rd"]["num_samples"]) * len(g["frames"]) and c["watchdog"] == 0
         grp.close()
+
+
+@pytest.mark.parametrize("n,rpb", [(2, 8), (3, 8), (8, 8), (2, 3), (3, 5), (8, 1), (5, 2)])
+def test_group_of_virtual_devices_renders_the_golden_frames(T, sky, n, rpb):
+    """The in-library N > 1 path on ONE GPU: srt_group_create with a device list that repeats device 0 (here: no list and
+    more members than the box has devices, which wraps around). Row partition, per-member trace, collection into the root's
+    rank-major buffer (a device-to-device copy per member where ncclGather sits: RCCL refuses a list with duplicates),
+    unpermute, resolve, summed counters -- everything but the link. Heights 48 / 40 / 29 against n * rows_per_block cover
+    whole rounds of blocks, a ragged last round, members that own nothing (8 x 8 rows > 48) and single-row blocks."""
+    for name in ("mixed", "spheres_accum", "ragged"):
+        g = CASES[name]
+        h, w = g["argb"].shape[:2]
+        grp = T.TracerGroup(w, h, n, rows_per_block=rpb)
+        grp.set_skybox(sky)
+        grp.options = g["rd"].copy()
+        grp.scene_data = g["sd"].copy()
+        grp.update_scene(g["shapes"], g["tris"], g["mats"])
+        grp.clear_canvas()
+        out = None
+        for i, tm in enumerate(g["frames"]):
+            grp.options["time"] = np.uint32(tm)
+            out = grp.render(i + 1)
+        assert bits_equal(grp.read_canvas(), g["canvas"]), (name, n, rpb)
+        assert np.array_equal(out.reshape(g["argb"].shape), g["argb"]), (name, n, rpb)
+        c = grp.counters()
+        assert c["paths"] == w * h * int(g["rd"]["num_samples"]) * len(g["frames"]) and c["watchdog"] == 0
+        grp.close()
+
+
+def test_group_of_virtual_devices_with_models_and_bvh(T, sky):
+    """srt_group_update_scene prepares the scene ONCE (hierarchy build, shape blocks, material thresholds) and uploads it to
+    every member: three members, array scan and BVH, the mesh goldens; a second update with a moved model refits on member 0's
+    cache and reaches every member."""
+    for accel in (0, 1):
+        for name in ("mesh_smooth", "boxes"):
+            g = CASES[name]
+            h, w = g["argb"].shape[:2]
+            grp = T.TracerGroup(w, h, 3, rows_per_block=4)
+            grp.set_skybox(sky)
+            grp.set_acceleration(accel)
+            grp.options, grp.scene_data = g["rd"].copy(), g["sd"].copy()
+            moved = g["shapes"].copy()
+            m = moved["type"] == 2
+            moved["transform"][m, 3, 0] += np.float32(0.25)  # somewhere else first (the box no longer fits: only the refit path matters here) ...
+            grp.update_scene(moved, g["tris"], g["mats"])
+            grp.update_scene(g["shapes"], g["tris"], g["mats"])  # ... then where the golden has it
+            grp.clear_canvas()
+            grp.options["time"] = np.uint32(g["frames"][0])
+            out = grp.render(1)
+            assert bits_equal(grp.read_canvas(), g["canvas"]), (name, accel)
+            assert np.array_equal(out.reshape(g["argb"].shape), g["argb"]), (name, accel)
+            grp.close()
+
+
+def test_group_update_scene_error_reaches_the_caller(T, sky):
+    """A scene the host pass refuses (a shape with a material index beyond the table) fails srt_group_update_scene with the
+    member's message, and the group keeps rendering its previous scene."""
+    g = CASES["ragged"]
+    h, w = g["argb"].shape[:2]
+    grp = T.TracerGroup(w, h, 3, rows_per_block=8)
+    grp.set_skybox(sky)
+    grp.options, grp.scene_data = g["rd"].copy(), g["sd"].copy()
+    grp.update_scene(g["shapes"], g["tris"], g["mats"])
+    bad = g["shapes"].copy()
+    bad["material"][0] = len(g["mats"]) + 3
+    with pytest.raises(T.SrtError, match="material"):
+        grp.update_scene(bad, g["tris"], g["mats"])
+    grp.clear_canvas()
+    grp.options["time"] = np.uint32(g["frames"][0])
+    grp.render(1)
+    assert bits_equal(grp.read_canvas(), g["canvas"])
+    grp.close()
 
 
 def test_comm_gather_world_of_one_equals_direct_read(T, sky):

@@ -87,6 +87,11 @@ typedef srt_bvh_node BvhNode; /* include/srt_types.h */
 
 enum { SRT_CTR_RAYS = 0, SRT_CTR_SKY, SRT_CTR_TRI, SRT_CTR_TRI_PASS_U, SRT_CTR_NAN, SRT_CTR_PATHS, SRT_CTR_QUEUE, SRT_CTR_WATCHDOG, SRT_CTR_QUEUE2, SRT_CTR_COUNT }; /* QUEUE / QUEUE2: work cursors of even / odd sample batches */
 
+/* TraceParams.material_flags. A draw whose outcome the scene fixes is not made: the generator is advanced past it (the draws
+ * behind it see the same states) and the outcome is a constant. */
+#define SRT_MF_NO_SPECULAR 1 /* every material's specular threshold is 0: `specular > random_float` is false for every output of the generator */
+#define SRT_MF_PLAIN_COLORS 2 /* every material colour component is finite and not -0: mix(colour, 1, 0) = fma(1 - colour, 0, colour) is the colour itself, bit for bit */
+
 struct TraceParams {
 	srt_render_data rd;
 	srt_scene_data sd;
@@ -117,7 +122,7 @@ struct TraceParams {
 	 * recomputed (and kept in VGPRs / spilled masks) by every persistent wave */
 	float f_width, f_height, f_sky_w, f_sky_h; /* exact int -> float conversions */
 	int32_t sun_focus_int;                     /* dm_pow_small_int(sd.sun_focus): 1..32, or 0 = general pow */
-	int32_t _pad2;
+	int32_t material_flags;                    /* SRT_MF_*: what srt_update_scene found true of EVERY material of the scene (kernels.hip SHADE) */
 	int32_t num_models;
 	int32_t rank, world, rows_per_block, owned_rows;
 	int32_t use_bvh;          /* model records carry a BVH root instead of a first world triangle */

@@ -968,7 +968,7 @@ __device__ __forceinline__ f3 sky_box(const TraceParams &p_live, f3 dir) {
 #define SRT_HQ_CAP 64
 #endif
 #ifndef SRT_HQ_CAP_MODELS
-#define SRT_HQ_CAP_MODELS 56
+#define SRT_HQ_CAP_MODELS 64 // (40 / 48 / 56 / 64 at full size: configs[2] array scan 103.3 / 103.1 / 103.2 / 103.2 ms -- the scan does not care)
 #endif
 // Array-scan kernels: a model of at least this many triangles ("big", srt_abi.hip packs it alone in its block) is not
 // scanned by the few lanes whose rays happen to enter its box in one EXTEND phase; those rays wait in one of the
@@ -981,7 +981,7 @@ __device__ __forceinline__ f3 sky_box(const TraceParams &p_live, f3 dir) {
 #define SRT_SCAN_FULL 64
 #endif
 #ifndef SRT_HQ_CAP_BVH
-#define SRT_HQ_CAP_BVH 56
+#define SRT_HQ_CAP_BVH 64 // (40 / 48 / 56 / 64: configs[2] BVH 34.9 / 34.6 / 34.6 / 34.3 ms, configs[4] BVH 34.6 / 34.7 / 34.5 / 34.1)
 #endif
 // entries of the sky ring (<= 64): the ring is resolved when full, one entry per lane
 #ifndef SRT_RING_CAP
@@ -1091,6 +1091,7 @@ __global__ __launch_bounds__(64, USE_BVH ? SRT_TRACE_WAVES_PER_SIMD_BVH : HAS_MO
 	const int n_shapes = p.sd.num_shapes;
 	const bool all_materials_ok = p.all_materials_ok != 0;
 	const bool unit_materials = p.unit_materials != 0; // the materials carry integer thresholds in place of their three probabilities (bernoulli)
+	const bool no_specular = (p.material_flags & (SRT_MF_NO_SPECULAR | SRT_MF_PLAIN_COLORS)) == (SRT_MF_NO_SPECULAR | SRT_MF_PLAIN_COLORS); // (wave-uniform) see SHADE
 	const BlockGroup *__restrict__ runs = p.runs;
 	const float *__restrict__ run_data = p.run_data;
 	const float *__restrict__ wtris = p.wtris;
@@ -1621,7 +1622,15 @@ __global__ __launch_bounds__(64, USE_BVH ? SRT_TRACE_WAVES_PER_SIMD_BVH : HAS_MO
 						f3 reflected_dir = reflect3(dir, nrm);
 						// the three material draws (render.cl:427-430; nothing else draws in between)
 						bool is_metallic, is_specular, is_transparent;
-						if (unit_materials) { // (wave-uniform)
+						if (no_specular) {
+							// (wave-uniform) No material of the scene is specular: `0 > random_float` is false whatever the generator returns, so
+							// the draw is not made -- the state steps over it (the compiler folds the two steps to the transmittance draw into
+							// one multiply-add) -- and mix(colour, 1, 0) below is the colour (SRT_MF_PLAIN_COLORS). BASELINE configs[0..4].
+							is_metallic = bernoulli(metallic, true, seed);
+							seed = seed * 747796405u + 2891336453u; // random_bits' state step, its output unused
+							is_specular = false;
+							is_transparent = bernoulli(transmittance, true, seed);
+						} else if (unit_materials) { // (wave-uniform)
 							is_metallic = bernoulli(metallic, true, seed), is_specular = bernoulli(specular, true, seed), is_transparent = bernoulli(transmittance, true, seed);
 						} else {
 							is_metallic = bernoulli(metallic, false, seed), is_specular = bernoulli(specular, false, seed), is_transparent = bernoulli(transmittance, false, seed);
@@ -1630,7 +1639,8 @@ __global__ __launch_bounds__(64, USE_BVH ? SRT_TRACE_WAVES_PER_SIMD_BVH : HAS_MO
 						if (!is_transparent) {
 							SRT_REGION(SHADE_OPAQUE);
 							dir = mix3(random_dir, rough_dir, (is_metallic || is_specular) ? 1.0f : 0.0f);
-							mask = mask * mix3(mcolor, mk(1.0f, 1.0f, 1.0f), is_specular ? 1.0f : 0.0f);
+							if (no_specular) mask = mask * mcolor; // = mix3(mcolor, 1, 0) for finite colours that are not -0
+							else mask = mask * mix3(mcolor, mk(1.0f, 1.0f, 1.0f), is_specular ? 1.0f : 0.0f);
 						} else {
 							SRT_REGION(SHADE_GLASS);
 							f3 in_dir = reflect3(rough_dir, nrm);

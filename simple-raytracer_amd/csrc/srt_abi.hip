@@ -620,6 +620,7 @@ struct ScenePrep {
 	uint64_t total_wtris = 0, max_tris = 0;
 	int num_models = 0;
 	bool use_bvh = false, unit_materials = false, all_materials_ok = true;
+	int material_flags = 0;
 	uint64_t bvh_info[7] = {0, 0, 0, 0, 0, 0, 0};
 };
 
@@ -838,6 +839,16 @@ static int prepare_scene(srt_tracer *t, ScenePrep &sp, const srt_shape *shapes, 
 	for (const auto &m : dev_mats)
 		if (threshold(m.metallic) >> 32 || threshold(m.specular) >> 32 || threshold(m.transmittance) >> 32) unit_materials = false;
 	sp.unit_materials = unit_materials;
+	{
+		// what holds for every material (SRT_MF_*): draws the scene decides are not made by the kernel
+		bool no_specular = unit_materials, plain = true;
+		for (const auto &m : dev_mats) {
+			if (threshold(m.specular) != 0) no_specular = false;
+			for (float c : {m.color.x, m.color.y, m.color.z})
+				if (!std::isfinite(c) || (c == 0.0f && std::signbit(c))) plain = false;
+		}
+		sp.material_flags = (no_specular ? SRT_MF_NO_SPECULAR : 0) | (plain ? SRT_MF_PLAIN_COLORS : 0);
+	}
 	for (auto &m : dev_mats) {
 		if (unit_materials) {
 			const uint32_t tm = (uint32_t)threshold(m.metallic), ts = (uint32_t)threshold(m.specular), tt = (uint32_t)threshold(m.transmittance);
@@ -941,6 +952,7 @@ static int upload_scene_end(srt_tracer *t, const ScenePrep &sp, size_t n_shapes,
 	for (int k = 0; k < 7; k++) t->bvh_info[k] = sp.bvh_info[k];
 	t->all_materials_ok = sp.all_materials_ok;
 	t->unit_materials = sp.unit_materials;
+	t->material_flags = sp.material_flags;
 	t->num_runs = (int)sp.groups.size();
 	t->num_materials = n_materials;
 	t->scene_set = true;
@@ -1036,6 +1048,7 @@ int srt_trace(srt_tracer *t, const srt_render_data *options) {
 	srt_magic_u31(t->rows_per_block > 0 ? (uint32_t)t->rows_per_block : 1u, &p.rpb_magic, &p.rpb_shift);
 	p.all_materials_ok = t->scene_set && t->all_materials_ok ? 1 : 0;
 	p.unit_materials = t->scene_set && t->unit_materials ? 1 : 0;
+	p.material_flags = t->scene_set ? t->material_flags : 0;
 	p.f_sky_w = (float)t->sky_w;
 	p.f_sky_h = (float)t->sky_h;
 	p.sun_focus_int = dm_pow_small_int(p.sd.sun_focus);

@@ -83,6 +83,7 @@ struct srt_tracer {
 	int num_models = 0;
 	bool all_materials_ok = false; // no shape of the scene has a negative material index
 	bool unit_materials = false;   // the device material table holds bernoulli() thresholds (srt_update_scene)
+	int material_flags = 0;        // SRT_MF_* (device_types.h)
 	uint64_t scan_tris = 0; // array scan: triangles of the models a ray can be made to scan (all of them), for the launch-length bound
 	bool scene_set = false;
 	bool count_tris = false;

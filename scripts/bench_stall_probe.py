@@ -45,6 +45,31 @@ def steps(t, n):
             "first_five_steps_ms": [round(float(x), 3) for x in r[:5, 4]]}
 
 
+if "--torch" in sys.argv:
+    # round 3's bench.py, step by step: torch's context and stream, the headline handle bound to them, one 1024-spp dispatch,
+    # 13 s of CPU work, the handle destroyed, the canvas tensor dropped, torch.cuda.empty_cache() -- then a NEW handle whose
+    # third step onwards is timed (warm-up by count: two steps)
+    import torch
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(0)
+    stream = torch.cuda.Stream(device=dev)
+    torch.cuda.set_stream(stream)
+    big = handle(1920, 1080, 1024)
+    big.bind_stream(stream.cuda_stream)
+    canvas_t = torch.zeros((1080, 1920, 4), dtype=torch.float32, device=dev)
+    big.bind_canvas(canvas_t.data_ptr(), canvas_t.numel() * 4)
+    big.clear_canvas(); big.trace(); big.resolve(1); big.synchronize()
+    time.sleep(13.0)
+    t0 = time.perf_counter()
+    big.close(); del canvas_t; torch.cuda.empty_cache()
+    free_ms = (time.perf_counter() - t0) * 1e3
+    small = handle(256, 256, 16)
+    for _ in range(2):
+        small.clear_canvas(); small.trace(); small.resolve(1)
+    small.synchronize()
+    print(json.dumps({"situation": f"round 3's sequence (torch context, headline handle + canvas freed in {free_ms:.1f} ms after 13 s idle, two warm-up steps)", **steps(small, 30)}))
+    small.close()
+    sys.exit(0)
 small = handle(256, 256, 16)
 small.clear_canvas(); small.trace(); small.resolve(1); small.synchronize()  # first use: allocations
 print(json.dumps({"situation": "cold (first steps of the handle, two launches behind it)", **steps(small, 30)}))

@@ -421,3 +421,28 @@ def test_caller_owned_canvas_stream_and_external_resolve(T, sky):
         t.trace()
         assert bits_equal(t.read_canvas(), g["canvas"])
         t.close()
+
+
+@pytest.mark.parametrize("case", ["plain", "minus_zero_colour", "nan_colour", "tiny_specular", "one_specular", "no_glass"])
+def test_draws_the_scene_decides(T, sky, oracle, case):
+    """srt_update_scene tells the kernel what holds for EVERY material (device_types.h SRT_MF_*): with no specular material
+    the specular draw is not made (the generator steps over it) and mix(colour, 1, 0) is the colour itself -- valid for finite
+    colours that are not -0 only. Each edge of that rule against the oracle, bit for bit."""
+    shapes, tris, mats = S.sphere_scene()
+    mats = mats.copy()
+    if case == "minus_zero_colour":
+        mats["color"][1] = (-0.0, 0.5, 1.0)  # fma(1 - (-0), 0, -0) = +0: the shortcut would keep -0
+    if case == "nan_colour":
+        mats["color"][2] = (np.nan, 0.5, np.inf)
+    if case == "tiny_specular":
+        mats["specular"][0] = 1e-12  # true for exactly one output of the generator (u = 0): the draw must be made
+    if case == "one_specular":
+        mats["specular"][3] = 0.35
+    if case == "no_glass":
+        mats["transmittance"][:] = 0.0
+    rd = R.render_data(64, 40, 24, 10, camera_to_world=S.default_camera(), time=4711)
+    g = dict(shapes=shapes, tris=tris, mats=mats, rd=rd, sd=R.scene_data(len(shapes)))
+    t = make_tracer(T, g, sky)
+    t.trace()
+    assert bits_equal(t.read_canvas(), oracle.render(rd, g["sd"], shapes, tris, mats, sky)), case
+    t.close()

@@ -24,7 +24,7 @@ CSRC = PKG / "csrc"
 LIBDIR = PKG / "lib"
 LIB = LIBDIR / "libsrt_hip.so"
 SOURCES = ["kernels.hip", "srt_abi.hip", "srt_collect.hip"]
-HEADERS = ["detmath.h", "device_types.h", "srt_internal.h", "../../include/srt_abi.h", "../../include/srt_types.h"]
+HEADERS = ["detmath.h", "device_types.h", "srt_internal.h", "issue_probe.h", "../../include/srt_abi.h", "../../include/srt_types.h"]
 ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize", "-fPIC", "-fno-gpu-rdc", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function",
          "-pthread", "-Rpass-analysis=kernel-resource-usage"]  # -pthread: the host BVH build runs subtrees on std::async threads

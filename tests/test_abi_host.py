@@ -88,3 +88,17 @@ def test_partition_helpers(lib, height, world, rpb):
                 gathered[r * padded + lr] = y
     img = tracer.unpermute(gathered, height, world, rpb)
     assert (img == np.arange(height)[:, None]).all()
+
+
+def test_product_library_reads_no_development_knobs():
+    """The scheduling knobs (SRT_WAVES_PER_CU, SRT_SCAN_PAIRS, SRT_JOB_CAP_SUBS, SRT_POOL_BLOCKS, SRT_NO_SCAN_POOL) exist in the
+    -DSRT_DEV_KNOBS build only (lib/variants/dev): their names are not even in the product library, whose one environment
+    variable is SRT_RADIANCE_BUDGET_MB; the dev build says what it is in srt_version()."""
+    from simple_raytracer_amd import build, tracer
+    product = Path(build.build_hip()).read_bytes()
+    dev = Path(build.build_dev()).read_bytes()
+    knobs = [b"SRT_WAVES_PER_CU", b"SRT_SCAN_PAIRS", b"SRT_JOB_CAP_SUBS", b"SRT_POOL_BLOCKS", b"SRT_NO_SCAN_POOL"]
+    assert not [k for k in knobs if k in product]
+    assert all(k in dev for k in knobs)
+    assert b"SRT_RADIANCE_BUDGET_MB" in product
+    assert b"dev knobs" not in tracer.load_library().srt_version() and b"dev knobs" in tracer.load_dev_library().srt_version()

@@ -1229,10 +1229,14 @@ int srt_trace(srt_tracer *t, const srt_render_data *options) {
 		// measured 0.39 -> 0.35 ms against two rounds of single sub-jobs.
 		const unsigned long long sub = (unsigned long long)srt_sub_job_items(t->num_models > 0, t->bvh_active);
 		// A small dispatch ends in the tail of its longest paths, during which every resident wave still
-		// issues whole iterations for a few live lanes: fewer, faster waves win there (960x540x2spp:
-		// 2 / 3 / 4 / 5 waves per SIMD = 0.28 / 0.27 / 0.30 / 0.31 ms). At least ~320 items per wave, and
-		// never fewer than 2 waves per SIMD.
-		unsigned long long slots_b = p.total_items / 320ull;
+		// issues whole iterations for a few live lanes: round 2 measured fewer, faster waves as the winner there
+		// (960x540x2spp: 2 / 3 / 4 / 5 waves per SIMD = 0.28 / 0.27 / 0.30 / 0.31 ms, hence "at least ~320 items per wave");
+		// with round 4's loop (full SHADE phases, cheap bookkeeping) every resident wave pays again down to ~190 items
+		// each. Never fewer than 2 waves per SIMD.
+		unsigned long long items_per_wave = 192ull; // (round 4's kernel, 960x540x2 spp: 128 / 192 / 256 / 320 / 448 items per wave = 0.104 / 0.104 / 0.104 / 0.117 / 0.143 ms)
+		if (const char *env = dev_env("SRT_ITEMS_PER_WAVE"))
+			if (atoi(env) > 0) items_per_wave = (unsigned long long)atoi(env);
+		unsigned long long slots_b = p.total_items / items_per_wave;
 		if (slots_b < (unsigned long long)t->num_cus * 8ull) slots_b = (unsigned long long)t->num_cus * 8ull;
 		if (slots_b > (unsigned long long)slots) slots_b = (unsigned long long)slots;
 		unsigned long long job = (p.total_items / (slots_b * 8ull) / sub) * sub;

@@ -159,8 +159,8 @@ int srt_get_counters(srt_tracer *t, srt_counters *out);
 int srt_set_count_triangles(srt_tracer *t, int enable);
 int srt_reset_counters(srt_tracer *t);
 /* Diagnostics of the trace kernel's scheduling (not part of any result): out[0..4] = rays, sky, paths,
- * tri_tests, tri_pass_u as above; out[5] = paths that outlived their staging buffer and stored their
- * radiance themselves, plus (staging buffers written out early << 40); out[6] = iterations of the
+ * tri_tests, tri_pass_u as above; out[5] = 0 (rounds 1-3: paths that outlived their LDS staging buffer; since round 4
+ * every path stores its radiance itself); out[6] = iterations of the
  * waves' main loop; out[7] = SHADE phases executed (sums since the last srt_reset_counters); out[8] = persistent
  * waves per CU and out[9] = workgroups of the most recent trace launch; out[10..17] = per-phase wave cycles
  * (extend, sky ring, shade, park, deliver, refill, loop head, whole kernel) of a -DSRT_PHASE_CLOCK build; in the product
@@ -236,8 +236,11 @@ int srt_unpermute_device(const void *gathered, void *image, int width, int heigh
 
 /* One process driving several GPUs -- what a front-end that keeps the reference's single `Tracer`
  * object needs (host/tracer.hpp: Tracer(width, height, n_devices)). The group owns one handle per
- * device (devices == NULL: 0 .. n_devices-1), partitioned in interleaved blocks of rows_per_block
- * rows, and one communicator (ncclCommInitAll). Scene, skybox and options are replicated;
+ * device (devices == NULL: 0 .. n_devices-1, wrapping around when the node has fewer), partitioned in interleaved
+ * blocks of rows_per_block rows, and one communicator (ncclCommInitAll). A list that names a device more than once makes
+ * VIRTUAL devices: the members share GPUs, RCCL is not used, and the collection is a device-to-device copy per member
+ * where the gather would be -- the N > 1 path on fewer GPUs than members, down to one (tests, rehearsals). Scene
+ * (prepared on the host once per srt_group_update_scene), skybox and options are replicated;
  * srt_group_render = trace on every device, one gather to the group's first device, resolve there,
  * blocking read-back of width*height*4 bytes: the image equals the single-device one bit for bit. */
 typedef struct srt_group srt_group;

@@ -116,7 +116,7 @@ struct TraceParams {
 	uint32_t batch_samples;          /* samples per pixel in this batch */
 	uint32_t first_sample;           /* sample index of the batch's first sample */
 	uint32_t job_items;              /* items a wave reserves per atomic (multiple of the LDS sub-job size) */
-	uint32_t stage_off;              /* float4 offset of the staging slots inside dynamic LDS */
+	uint32_t stage_off;              /* float4 offset of the per-wave queues (sky ring, hit queue) inside dynamic LDS, behind the scene records */
 	int32_t sky_w, sky_h;
 	/* wave-uniform values precomputed on the host so they arrive in SGPRs instead of being
 	 * recomputed (and kept in VGPRs / spilled masks) by every persistent wave */
@@ -186,7 +186,7 @@ void srt_launch_reduce(const ReduceParams &p, void *stream);
 int srt_trace_waves_per_simd(int has_models, int use_bvh);
 int srt_trace_resident_waves_per_cu(const TraceParams &p, bool count_triangles); /* from the runtime's occupancy calculator */
 int srt_scan_suspend_min(void); /* array scan: models of at least this many triangles sit alone in their block and are flagged big */
-int srt_sub_job_items(int has_models, int use_bvh); /* items per LDS-staged sub-job; chunks per atomic are multiples of it */
+int srt_sub_job_items(int has_models, int use_bvh); /* items per sub-job (the unit a wave's chunk is handed to its lanes in); chunks per atomic are multiples of it */
 int srt_scan_queue_in_hbm(void); /* 1: TraceParams.scan_queue must point at SRT_SCAN_QUEUE_FLOATS floats per wave of the launch */
 /* per persistent wave: two scan stacks of SRT_SQ_CAP records x 20 fields, one park stack of SRT_PK_CAP records x 15 fields.
  * A scan stack is taken back when it holds 64 rays and one EXTEND phase pushes at most 64: 190 is the most one can hold. */

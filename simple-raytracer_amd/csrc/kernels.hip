@@ -943,10 +943,9 @@ __device__ __forceinline__ f3 sky_box(const TraceParams &p_live, f3 dir) {
 // other lanes masked off in every iteration, and a lane that freed up set up its camera ray
 // through an LDS staging slot).
 //
-// Finished radiances are staged in LDS as packed 12-byte items of a SUB-JOB (two buffers,
-// ping-pong) and leave as whole 64-byte lines. A path that outlives its sub-job's buffer does
-// not stall the wave: the buffer is written out when the wave needs it, and the straggler
-// stores its 12 bytes itself when it ends (it recognises that from its item number alone).
+// A path that ends stores its 12 bytes of radiance itself (store_radiance below; rounds 1-3 staged sub-jobs of 64 items in
+// LDS and wrote whole lines). SUB-JOBS of 64 consecutive items remain the unit in which a wave's chunk is handed to its
+// lanes: one scalar division per sub-job places it in the frame, and a lane's pixel is that pixel or the next one.
 #ifndef SRT_SUB_PLAIN
 #define SRT_SUB_PLAIN 64
 #endif
@@ -1062,8 +1061,8 @@ __device__ __forceinline__ void resolve_ring(const TraceParams &p, const float *
 }
 } // namespace
 
-// Waves per SIMD the register allocator is asked for. LDS per wave (two staging buffers, sky
-// ring, hit queue, scene records) is ~10 KB, which is what bounds residency.
+// Waves per SIMD the register allocator is asked for. LDS per wave (sky ring, hit queue, scene records: 7.4 KB in sphere /
+// plane scenes) bounds residency at 21 per CU; the sphere kernel's 78 VGPRs would allow a sixth wave per SIMD.
 #ifndef SRT_TRACE_WAVES_PER_SIMD
 #define SRT_TRACE_WAVES_PER_SIMD 5
 #endif
@@ -1082,7 +1081,7 @@ __device__ __forceinline__ void resolve_ring(const TraceParams &p, const float *
 // instantiation from the scene.
 template <bool COUNT_TRIS, bool USE_LDS, bool HAS_MODELS, bool USE_BVH>
 __global__ __launch_bounds__(64, USE_BVH ? SRT_TRACE_WAVES_PER_SIMD_BVH : HAS_MODELS ? SRT_TRACE_WAVES_PER_SIMD_MODELS : SRT_TRACE_WAVES_PER_SIMD) void srt_trace_kernel(const TraceParams p) {
-	extern __shared__ float4 lds[]; // [2*n_shapes] winner records, [4*n_materials] materials, staging, sky ring, hit queue
+	extern __shared__ float4 lds[]; // [2*n_shapes] winner records, [4*n_materials] materials, (sphere / plane scenes: group headers, shape blocks,) sky ring, hit queue
 	constexpr uint32_t SUB = USE_BVH ? SRT_SUB_BVH : HAS_MODELS ? SRT_SUB_MODELS : SRT_SUB_PLAIN;
 	const int width = p.rd.width;
 	const int lane = threadIdx.x;
@@ -1127,8 +1126,7 @@ __global__ __launch_bounds__(64, USE_BVH ? SRT_TRACE_WAVES_PER_SIMD_BVH : HAS_MO
 	// on (nearly) the same camera ray. Persistent waves reserve chunks of p.job_items items from
 	// ONE global cursor (the first chunk of a wave is its own: chunk number = workgroup number, so
 	// thousands of waves starting together do not queue up on one atomic) and work through them in
-	// sub-jobs of SUB items, whose radiances are staged in LDS. srt_reduce_kernel adds the
-	// radiances up per pixel in sample order.
+	// sub-jobs of SUB items. srt_reduce_kernel adds the radiances up per pixel in sample order.
 	const uint32_t total_items = (uint32_t)p.total_items;
 	const uint32_t nbs = p.batch_samples;
 	const unsigned long long own_chunks_end = (unsigned long long)gridDim.x * p.job_items;

@@ -1593,9 +1593,8 @@ int srt_acceleration_info(const srt_tracer *t, uint64_t out[7]) {
 	return SRT_OK;
 }
 
-/* diagnostics: sums of the eight per-wave counter slots since the last reset (slot 5 = stragglers that stored their
- * radiance themselves + (staging buffers written out with paths still under way << 40), 6 = wave iterations,
- * 7 = SHADE phases) */
+/* diagnostics: sums of the eight per-wave counter slots since the last reset (slot 5 = unused since round 4, 6 = wave
+ * iterations, 7 = SHADE phases) */
 int srt_debug_counters(srt_tracer *t, uint64_t out[18]) {
 	if (!t || !out) return SRT_ERR_INVALID;
 	SRT_HIP(t, hipSetDevice(t->device));

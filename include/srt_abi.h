@@ -173,8 +173,11 @@ int srt_debug_counters(srt_tracer *t, uint64_t out[18]);
 int srt_debug_region_counters(srt_tracer *t, uint64_t *out, int capacity, int *written);
 /* Device time of the most recent srt_trace (trace kernel(s) + ordered reduction) and of
  * the most recent resolve, from HIP events recorded on the handle's stream (milliseconds).
- * Synchronises the stream. */
+ * Synchronises the stream. The render calls (srt_render, srt_render_async, srt_render_pipelined) fuse the resolve into
+ * the last reduction and record no timer events unless srt_set_kernel_timers(t, 1) was called (four event records are
+ * 10-17 us of a 150 us interactive frame): after them both figures read 0 by default. */
 int srt_last_kernel_ms(srt_tracer *t, float *trace_ms, float *resolve_ms);
+int srt_set_kernel_timers(srt_tracer *t, int enable);
 /* The same for srt_trace_kernel alone: one launch per sample batch of the dispatch. Batches that follow one another
  * (a dispatch of one batch, the usual case): the sum of each launch's own event pair, the ordered reductions between them
  * not counted. Overlapping batches (several batches: even and odd ones trace on two streams so that one batch's tail runs

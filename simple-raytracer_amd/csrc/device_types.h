@@ -172,6 +172,11 @@ struct ReduceParams {
 	uint32_t batch_samples;
 	int32_t num_samples;
 	uint32_t first_batch, last_batch;
+	unsigned long long *queue_reset; /* the work cursor the batch's trace launch used: zeroed here for the launch that uses it next (one
+	                                    command less per frame than a memset of 8 bytes in front of every trace launch) */
+	uint8_t *argb;                   /* last batch only, may be NULL: the pixel's A,R,G,B bytes as srt_resolve_kernel makes them of the new
+	                                    canvas value (srt_render: one launch less per frame) */
+	uint32_t num_steps;              /* the resolve's divisor (ticks_stopped) */
 };
 
 struct ResolveParams {

@@ -2002,6 +2002,14 @@ __global__ __launch_bounds__(64, USE_BVH ? SRT_TRACE_WAVES_PER_SIMD_BVH : HAS_MO
 #endif
 }
 
+namespace {
+__device__ __forceinline__ float aces1(float x) {
+	const float a = 2.51f, b = 0.03f, c = 2.43f, d = 0.59f, e = 0.14f;
+	return dm_clamp((x * (x * a + b)) / (x * (x * c + d) + e), 0.0f, 1.0f);
+}
+__device__ __forceinline__ uint32_t to_uchar(float v) { return (v == v) ? ((uint32_t)(int)v & 255u) : 0u; }
+} // namespace
+
 // ---------------------------------------------------------------------------------
 // Ordered reduction: lane = pixel, serial over the batch's samples in sample order, so
 // the float sums are the reference's `color += trace(...)` sequence bit for bit no matter
@@ -2009,6 +2017,7 @@ __global__ __launch_bounds__(64, USE_BVH ? SRT_TRACE_WAVES_PER_SIMD_BVH : HAS_MO
 // ---------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void srt_reduce_kernel(const ReduceParams p) {
 	const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+	if (q == 0u && p.queue_reset) *p.queue_reset = 0ull; // the trace launch this reduction follows is over: its cursor, ready for the next one
 	if (q >= p.num_pixels) return;
 	f3 c = mk(0.f, 0.f, 0.f);
 	float4 *run = reinterpret_cast<float4 *>(p.running) + q;
@@ -2062,6 +2071,11 @@ __global__ __launch_bounds__(256) void srt_reduce_kernel(const ReduceParams p) {
 		o.z += c.z;
 		*out = o; // render.cl:522
 		if (c.x != c.x || c.y != c.y || c.z != c.z) atomicAdd(&p.counters[SRT_CTR_NAN], 1ull);
+		if (p.argb) { // the resolve of this pixel (srt_resolve_kernel's expressions on the value just written), fused for srt_render
+			const float n = (float)p.num_steps;
+			const float r = sqrt_ieee(aces1(o.x / n)), g = sqrt_ieee(aces1(o.y / n)), b = sqrt_ieee(aces1(o.z / n));
+			reinterpret_cast<uint32_t *>(p.argb)[q] = 255u | (to_uchar(r * 255.0f) << 8) | (to_uchar(g * 255.0f) << 16) | (to_uchar(b * 255.0f) << 24);
+		}
 	} else {
 		*run = make_float4(c.x, c.y, c.z, 0.f);
 	}
@@ -2100,13 +2114,6 @@ __global__ __launch_bounds__(256) void srt_prepass_kernel(const PrepassParams p)
 // Resolve: canvas / num_steps -> ACES -> sqrt -> A,R,G,B bytes (render.cl:473-481,525-535)
 // 16 B in, 4 B out per pixel; HBM-bound.
 // ---------------------------------------------------------------------------------
-namespace {
-__device__ __forceinline__ float aces1(float x) {
-	const float a = 2.51f, b = 0.03f, c = 2.43f, d = 0.59f, e = 0.14f;
-	return dm_clamp((x * (x * a + b)) / (x * (x * c + d) + e), 0.0f, 1.0f);
-}
-__device__ __forceinline__ uint32_t to_uchar(float v) { return (v == v) ? ((uint32_t)(int)v & 255u) : 0u; }
-} // namespace
 
 __global__ __launch_bounds__(256) void srt_resolve_kernel(const ResolveParams p) {
 	const float4 *__restrict__ canvas = reinterpret_cast<const float4 *>(p.canvas);

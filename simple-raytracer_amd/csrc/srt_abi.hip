@@ -1010,7 +1010,11 @@ int srt_clear_canvas(srt_tracer *t) {
 	return clear_canvas_impl(t);
 }
 
-int srt_trace(srt_tracer *t, const srt_render_data *options) {
+int srt_trace(srt_tracer *t, const srt_render_data *options) { return srt_trace_fused(t, options, nullptr, 0u); }
+
+// srt_trace; with fused_argb != NULL the last reduction also resolves every pixel it has just accumulated into fused_argb
+// (owned pixels x 4 bytes, device memory) with the divisor ticks_stopped: what srt_resolve would do in a launch of its own
+int srt_trace_fused(srt_tracer *t, const srt_render_data *options, uint8_t *fused_argb, uint32_t ticks_stopped) {
 	if (!t) return SRT_ERR_INVALID;
 	if (!options) return fail(t, SRT_ERR_INVALID, "srt_trace: options is NULL");
 	if (options->width != t->width || options->height != t->height)
@@ -1159,8 +1163,14 @@ int srt_trace(srt_tracer *t, const srt_render_data *options) {
 	rp.running = t->running.ptr;
 	rp.canvas = t->canvas;
 	rp.counters = t->counters.ptr;
+	// The kernel timers (srt_last_kernel_ms, srt_last_trace_kernel_ms) are four event records per dispatch: 10-17 us of a 150 us
+	// interactive frame. srt_trace always takes them; the render calls only when asked to (srt_set_kernel_timers).
+	const bool timed = !fused_argb || t->timers_in_render;
 	rp.num_pixels = (uint32_t)pixels;
 	rp.num_samples = ns;
+	rp.queue_reset = nullptr;
+	rp.argb = nullptr;
+	rp.num_steps = ticks_stopped;
 
 	while (t->ev_k.size() < 2 * (size_t)n_batches) { // std::vector growth is the only throwing step: srt_trace's callers catch nothing
 		hipEvent_t ev = nullptr;
@@ -1173,11 +1183,12 @@ int srt_trace(srt_tracer *t, const srt_render_data *options) {
 		}
 	}
 	t->ev_k_used = 0;
-	SRT_HIP(t, hipEventRecord(t->ev_t0, t->stream));
+	if (timed) SRT_HIP(t, hipEventRecord(t->ev_t0, t->stream));
 	if (n_batches == 0) {
 		// num_samples <= 0: no paths; the reduction still applies colour = 0 / num_samples (render.cl:520-522)
 		rp.batch_samples = 0;
 		rp.first_batch = rp.last_batch = 1;
+		rp.argb = fused_argb;
 		srt_launch_reduce(rp, t->stream);
 	}
 	// Several sample batches: even and odd batches trace on two streams of their own, each into its own radiance buffer,
@@ -1267,13 +1278,16 @@ int srt_trace(srt_tracer *t, const srt_render_data *options) {
 		p.job_items = (uint32_t)job;
 		const unsigned long long waves_needed = (p.total_items + 63ull) / 64ull;
 		const int num_waves = (int)(waves_needed < slots_b ? waves_needed : slots_b);
-		SRT_HIP(t, hipMemsetAsync(p.queue, 0, sizeof(unsigned long long), ts));
+		// the work cursor is zero: the reduction behind the launch that used it last has reset it (srt_reduce_kernel). Only a launch
+		// whose reduction was never enqueued (an error in between) leaves it dirty.
+		if (t->queue_dirty[par]) SRT_HIP(t, hipMemsetAsync(p.queue, 0, sizeof(unsigned long long), ts));
+		t->queue_dirty[par] = true;
 		if (p.pool_blocks) SRT_HIP(t, hipMemsetAsync(p.scan_queue, 0, (size_t)SRT_POOL_CTL_WORDS * sizeof(uint32_t), ts));
-		SRT_HIP(t, hipEventRecord(t->ev_k[2 * b], ts));
+		if (timed) SRT_HIP(t, hipEventRecord(t->ev_k[2 * b], ts));
 		t->last_grid = num_waves;
 		srt_launch_trace(p, t->count_tris, num_waves, ts);
 		SRT_HIP(t, hipGetLastError());
-		SRT_HIP(t, hipEventRecord(t->ev_k[2 * b + 1], ts));
+		if (timed) SRT_HIP(t, hipEventRecord(t->ev_k[2 * b + 1], ts));
 		if (overlap) {
 			SRT_HIP(t, hipEventRecord(t->ev_batch_traced[par], ts));
 			SRT_HIP(t, hipStreamWaitEvent(t->stream, t->ev_batch_traced[par], 0));
@@ -1282,13 +1296,16 @@ int srt_trace(srt_tracer *t, const srt_render_data *options) {
 		rp.batch_samples = nbs;
 		rp.first_batch = (b == 0);
 		rp.last_batch = (b == n_batches - 1);
+		rp.queue_reset = p.queue;
+		rp.argb = rp.last_batch ? fused_argb : nullptr;
 		srt_launch_reduce(rp, t->stream);
 		SRT_HIP(t, hipGetLastError());
+		t->queue_dirty[par] = false; // (no pixels: neither launch ran, the cursor is untouched)
 		if (overlap) SRT_HIP(t, hipEventRecord(t->ev_batch_reduced[par], t->stream));
 	}
-	SRT_HIP(t, hipEventRecord(t->ev_t1, t->stream));
-	t->have_trace_ev = true;
-	t->have_kernel_ev = n_batches > 0;
+	if (timed) SRT_HIP(t, hipEventRecord(t->ev_t1, t->stream));
+	t->have_trace_ev = timed;
+	t->have_kernel_ev = timed && n_batches > 0;
 	return SRT_OK;
 }
 
@@ -1336,10 +1353,9 @@ int srt_synchronize(srt_tracer *t) {
 int srt_render(srt_tracer *t, const srt_render_data *options, uint32_t ticks_stopped, uint8_t *argb_out) {
 	if (!t) return SRT_ERR_INVALID;
 	if (!argb_out) return fail(t, SRT_ERR_INVALID, "srt_render: argb_out is NULL");
-	int rc = srt_trace(t, options);
+	int rc = srt_trace_fused(t, options, t->argb.ptr, ticks_stopped); // trace, ordered reduction and resolve: the last two in one launch
 	if (rc) return rc;
-	rc = srt_resolve(t, ticks_stopped);
-	if (rc) return rc;
+	t->have_resolve_ev = false;
 	// blocking read-back, as queue.enqueue_read_buffer (src/tracer.cpp:115)
 	SRT_HIP(t, hipMemcpyAsync(argb_out, t->argb.ptr, owned_pixels(t) * 4, hipMemcpyDeviceToHost, t->stream));
 	SRT_HIP(t, hipStreamSynchronize(t->stream));
@@ -1349,10 +1365,9 @@ int srt_render(srt_tracer *t, const srt_render_data *options, uint32_t ticks_sto
 int srt_render_async(srt_tracer *t, const srt_render_data *options, uint32_t ticks_stopped, uint8_t *argb_out) {
 	if (!t) return SRT_ERR_INVALID;
 	if (!argb_out) return fail(t, SRT_ERR_INVALID, "srt_render_async: argb_out is NULL");
-	int rc = srt_trace(t, options);
+	int rc = srt_trace_fused(t, options, t->argb.ptr, ticks_stopped);
 	if (rc) return rc;
-	rc = srt_resolve(t, ticks_stopped);
-	if (rc) return rc;
+	t->have_resolve_ev = false;
 	SRT_HIP(t, hipMemcpyAsync(argb_out, t->argb.ptr, owned_pixels(t) * 4, hipMemcpyDeviceToHost, t->stream));
 	return SRT_OK; // argb_out is valid after srt_synchronize()
 }
@@ -1422,6 +1437,12 @@ int srt_last_kernel_ms(srt_tracer *t, float *trace_ms, float *resolve_ms) {
 		*resolve_ms = 0.f;
 		if (t->have_resolve_ev) SRT_HIP(t, hipEventElapsedTime(resolve_ms, t->ev_r0, t->ev_r1));
 	}
+	return SRT_OK;
+}
+
+int srt_set_kernel_timers(srt_tracer *t, int enable) {
+	if (!t) return SRT_ERR_INVALID;
+	t->timers_in_render = enable != 0;
 	return SRT_OK;
 }
 

@@ -510,9 +510,7 @@ int srt_render_pipelined(srt_tracer *t, const srt_render_data *options, uint32_t
 	}
 	// enqueue frame N: trace + resolve into this frame's own ARGB buffer on the handle's stream, its copy on the copy stream
 	const int slot = (int)(c->frames_enqueued & 1);
-	int rc = srt_trace(t, options);
-	if (rc != SRT_OK) return rc;
-	rc = srt_resolve_external(t, t->canvas, (uint32_t)((size_t)t->owned_rows * t->width), ticks_stopped, c->dev_argb[slot]);
+	int rc = srt_trace_fused(t, options, c->dev_argb[slot], ticks_stopped); // the last reduction resolves into this frame's own image
 	if (rc != SRT_OK) return rc;
 	SRT_HIP(t, hipEventRecord(c->resolved[slot], t->stream));
 	SRT_HIP(t, hipStreamWaitEvent(c->copy_stream, c->resolved[slot], 0));

@@ -74,6 +74,8 @@ struct srt_tracer {
 	// dispatches of several sample batches: even / odd batches trace on two streams of their own so that one batch's tail
 	// (its last long paths, a few lanes per wave) runs under the next batch's start; the reductions stay in order on `stream`
 	hipStream_t batch_stream[2] = {nullptr, nullptr};
+	bool timers_in_render = false; // srt_render / srt_render_async / srt_render_pipelined record the kernel timers' events too (srt_set_kernel_timers)
+	bool queue_dirty[2] = {false, false}; // a trace launch used the work cursor and no reduction has reset it since (srt_trace)
 	hipEvent_t ev_batch_traced[2] = {nullptr, nullptr}, ev_batch_reduced[2] = {nullptr, nullptr}, ev_batch_fork = nullptr;
 	bool batches_overlapped = false; // the last srt_trace ran that way (srt_last_trace_kernel_ms: a span, not a sum)
 	size_t ev_k_used = 0;         // events of the last srt_trace
@@ -105,6 +107,8 @@ static inline int fail(srt_tracer *t, int code, const std::string &msg) { return
 
 
 void srt_collect_release(srt_tracer *t);
+/* srt_trace whose last reduction also resolves into fused_argb (device, owned pixels x 4 bytes; NULL: plain srt_trace) */
+extern "C" int srt_trace_fused(srt_tracer *t, const srt_render_data *options, uint8_t *fused_argb, uint32_t ticks_stopped);
 /* one scene for several handles: the host pass once (members[0]'s acceleration mode and hierarchy cache), the uploads of all
  * members enqueued before the first is waited for (srt_abi.hip; srt_group_update_scene). *failed_member = the member an error came from */
 extern "C" int srt_update_scene_many(srt_tracer *const *members, size_t n_members, const srt_shape *shapes, size_t n_shapes, const srt_triangle *triangles,

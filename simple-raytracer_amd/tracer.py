@@ -25,7 +25,7 @@ LIB_PATH = Path(os.environ["SRT_LIB"]) if os.environ.get("SRT_LIB") else PKG / "
 ABI_SYMBOLS = [
     "srt_create", "srt_destroy", "srt_last_error", "srt_set_skybox", "srt_update_scene", "srt_clear_canvas",
     "srt_render", "srt_render_async", "srt_trace", "srt_set_radiance_budget", "srt_resolve", "srt_resolve_external", "srt_synchronize", "srt_read_canvas", "srt_read_argb",
-    "srt_get_counters", "srt_set_count_triangles", "srt_reset_counters", "srt_last_kernel_ms", "srt_last_trace_kernel_ms", "srt_last_trace_launches",
+    "srt_get_counters", "srt_set_count_triangles", "srt_reset_counters", "srt_last_kernel_ms", "srt_set_kernel_timers", "srt_last_trace_kernel_ms", "srt_last_trace_launches",
     "srt_device_buffers", "srt_bind_canvas", "srt_bind_stream", "srt_set_partition",
     "srt_partition_owned_rows", "srt_partition_padded_rows", "srt_partition_global_row",
     "srt_partition_unpermute", "srt_selftest_math", "srt_version", "srt_set_acceleration", "srt_acceleration_info", "srt_bvh_build_host", "srt_bvh_wide_host", "srt_debug_counters", "srt_debug_region_counters",
@@ -157,6 +157,8 @@ def _bind(lib):
     lib.srt_set_count_triangles.argtypes = [vp, i]
     lib.srt_reset_counters.argtypes = [vp]
     lib.srt_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    if hasattr(lib, "srt_set_kernel_timers"):
+        lib.srt_set_kernel_timers.argtypes = [vp, i]
     if hasattr(lib, "srt_last_trace_kernel_ms"):
         lib.srt_last_trace_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]
     lib.srt_device_buffers.argtypes = [vp, C.POINTER(vp), C.POINTER(sz), C.POINTER(vp), C.POINTER(sz)]
@@ -344,6 +346,10 @@ class Tracer:
         out = (C.c_uint64 * 16)()
         self._check(self.lib.srt_selftest_math(self._h, stride, out))
         return [int(v) for v in out]
+
+    def set_kernel_timers(self, enable=True):
+        """the render calls record the kernel timers' events too (default: only trace() does)"""
+        self._check(self.lib.srt_set_kernel_timers(self._h, int(bool(enable))))
 
     def last_kernel_ms(self):
         a, b = C.c_float(), C.c_float()

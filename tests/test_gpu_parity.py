@@ -446,3 +446,28 @@ def test_draws_the_scene_decides(T, sky, oracle, case):
     t.trace()
     assert bits_equal(t.read_canvas(), oracle.render(rd, g["sd"], shapes, tris, mats, sky)), case
     t.close()
+
+
+def test_render_fuses_the_resolve_and_times_only_on_request(T, sky):
+    """srt_render = trace + ordered reduction + resolve with the last two in ONE launch (the reduction resolves each pixel it has
+    just accumulated) and no timer events -- unless srt_set_kernel_timers asks for them. Bytes and canvas equal the golden's
+    either way, and equal trace() + resolve() as two calls."""
+    g = CASES["spheres_accum"]
+    for timers in (False, True):
+        t = make_tracer(T, g, sky)
+        t.set_kernel_timers(timers)
+        out = None
+        for i, tm in enumerate(g["frames"]):
+            t.options["time"] = np.uint32(tm)
+            out = t.render(i + 1)
+        trace_ms, resolve_ms = t.last_kernel_ms()
+        assert (trace_ms > 0.0) == timers and resolve_ms == 0.0
+        assert bits_equal(t.read_canvas(), g["canvas"]) and np.array_equal(out.reshape(g["argb"].shape), g["argb"])
+        t.close()
+    t = make_tracer(T, g, sky)
+    for i, tm in enumerate(g["frames"]):
+        t.options["time"] = np.uint32(tm)
+        t.trace()
+        t.resolve(i + 1)
+    assert t.last_kernel_ms()[0] > 0.0 and np.array_equal(t.read_argb().reshape(g["argb"].shape), g["argb"])
+    t.close()

@@ -1,4 +1,5 @@
 # Regime probe (round 4): the sphere kernel at full size with 100 extra instructions of ONE kind per loop iteration
+# (build the variants first: python scripts/build_variants.py "d_base=-DSRT_DIAG" "k1=-DSRT_DIAG -DSRT_DUMMY_KIND=1" ... "k22=...")
 # (-DSRT_DUMMY_KIND=k builds, lib/variants/k<k>) against the plain build: what an instruction of each kind costs.
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/r04

@@ -471,3 +471,14 @@ def test_render_fuses_the_resolve_and_times_only_on_request(T, sky):
         t.resolve(i + 1)
     assert t.last_kernel_ms()[0] > 0.0 and np.array_equal(t.read_argb().reshape(g["argb"].shape), g["argb"])
     t.close()
+    # a dispatch that runs as several sample batches: only the LAST reduction resolves
+    t = make_tracer(T, g, sky)
+    h, w = g["argb"].shape[:2]
+    t.set_radiance_budget(w * h * 12)  # one sample per batch
+    out = None
+    for i, tm in enumerate(g["frames"]):
+        t.options["time"] = np.uint32(tm)
+        out = t.render(i + 1)
+    assert t.last_trace_launches()[0] == int(g["rd"]["num_samples"])
+    assert bits_equal(t.read_canvas(), g["canvas"]) and np.array_equal(out.reshape(g["argb"].shape), g["argb"])
+    t.close()

@@ -54,20 +54,42 @@ static_assert(sizeof(WinnerRec) == 32, "WinnerRec 32 B");
  * srt_bvh_build_host) and folds it into the WIDE form the kernel walks: 128-byte blocks, one cache
  * line and one fetch each.
  *   inner block  dwords 0-3 lo.x of children 0..3, 4-7 hi.x, 8-11 lo.y, 12-15 hi.y, 16-19 lo.z,
- *                20-23 hi.z, 24-27 their references, 28-31 zero
- *   leaf block   up to three triangles of SRT_BVH_TRI_FLOATS dwords {v0, e1, e2, j} (values as in
- *                SRT_WTRI_FLOATS above; j = index inside the model, for the reference's first-in-
- *                array-order tie rule and for the vertex normals), written by srt_prepass_kernel;
- *                unused slots stay zero
- *   reference    SRT_BVH_NONE = no child; else block index (absolute, < 2^28), bit 31 = leaf,
- *                bits 28-29 = triangles in the leaf
+ *                20-23 hi.z, 24 their tags (child k in byte k), 25 the block index of child 0 (the
+ *                children's blocks lie side by side: child k is block first + k), 26 how many
+ *                children there are, 27-31 zero. An empty slot holds a box no ray passes (lo =
+ *                FLT_MAX, hi = -FLT_MAX).
+ *                SoA so that one 16-byte quarter is one plane of all four children: a lane fetches
+ *                the NEAR planes (lo where its direction is positive, hi where negative) and the FAR
+ *                ones by address and needs no min / max to tell them apart.
+ *   leaf block   up to three triangles of SRT_BVH_TRI_FLOATS dwords {v0, e1, e2} (values as in
+ *                SRT_WTRI_FLOATS above), dwords 0-26; dwords 28-30 (SRT_BVH_LEAF_J) their indices j
+ *                inside the model, for the reference's first-in-array-order tie rule and for the
+ *                vertex normals; all written by srt_prepass_kernel; unused slots stay zero.
+ *                A step of the walk fetches the first SEVEN quarters of a block, whatever it is: the
+ *                indices are looked at only where a hit is accepted at exactly the distance of the
+ *                closest one so far, and by the shading.
+ *   tag          5 bits: bit 4 = the child is a leaf block, bits 2-3 = triangles in it, bits 0-1 =
+ *                the child's slot k. The walk sorts the children it enters by ONE dword each, the
+ *                entry distance's bits with the tag in place of the five lowest (distances are >= 0,
+ *                so the bits order like the values; rounding a distance DOWN by 2^-18 of itself only
+ *                lets a few more children in), and everything it needs to enter a child later -- the
+ *                kind of block, where it is -- is that dword and `first`.
+ *   root         the model record's reference, as srt_bvh_wide_host hands it out: SRT_BVH_NONE =
+ *                nothing to walk; else block index (absolute, <= SRT_BVH_INDEX_MAX so that byte
+ *                offsets fit 32 bits), bit 31 = leaf, bits 28-29 = triangles in the leaf
  * A lane keeps the children it still has to enter on a stack of SRT_BVH_STACK_CAP entries; the host
  * checks every hierarchy against that bound (srt_abi.hip fold_wide) and falls back to a balanced one. */
 typedef srt_bvh_node BvhNode; /* include/srt_types.h */
-#define SRT_BVH_TRI_FLOATS 10
+#define SRT_BVH_TRI_FLOATS 9
+#define SRT_BVH_LEAF_J 28 /* dword of a leaf block with the first triangle's index inside the model */
 #define SRT_BVH_NONE 0xffffffffu
 #define SRT_BVH_LEAF_BIT 0x80000000u
 #define SRT_BVH_INDEX_MASK 0x0fffffffu
+#define SRT_BVH_INDEX_MAX 0x01ffffffu /* 4 GB of blocks */
+#define SRT_BVH_KEY_INF 0x7f800000u   /* sort keys at or above: a child the ray does not enter */
+#define SRT_BVH_TAG_MASK 31u
+#define SRT_BVH_TAG_LEAF 16u
+#define SRT_BVH_TAG(ref, slot) ((((ref) >> 31) << 4) | ((((ref) >> 28) & 3u) << 2) | (slot)) /* of a reference in the root's form */
 #define SRT_BVH_STACK_CAP 64
 #ifndef SRT_BVH_LEAF_MAX
 #define SRT_BVH_LEAF_MAX 3 /* triangles per leaf block */

@@ -738,104 +738,139 @@ __device__ __forceinline__ void test_triangles(const float *__restrict__ wtris, 
 //  * the scan keeps the FIRST triangle of equal t (strict <, render.cl:254-256): a hit with
 //    t == tmin inside the same model replaces the incumbent only if its index j is lower.
 struct BvhStackEntry {
-	uint32_t ref;
-	float t;
+	uint32_t key;   // entry distance | tag (device_types.h)
+	uint32_t first; // block of the parent's child 0: the entry is block first + (key & 3)
 };
 
-__device__ __forceinline__ void bvh_child(float lox, float hix, float loy, float hiy, float loz, float hiz, uint32_t ref, f3 org, f3 inv, float tmin,
-                                          float &t_out, uint32_t &ref_out) {
-	const float x1 = (lox - org.x) * inv.x, x2 = (hix - org.x) * inv.x;
-	const float y1 = (loy - org.y) * inv.y, y2 = (hiy - org.y) * inv.y;
-	const float z1 = (loz - org.z) * inv.z, z2 = (hiz - org.z) * inv.z;
-	const float tn = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(x1, x2), __builtin_fminf(y1, y2)), __builtin_fmaxf(__builtin_fminf(z1, z2), 0.0f));
-	const float tf = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(x1, x2), __builtin_fmaxf(y1, y2)), __builtin_fminf(__builtin_fmaxf(z1, z2), tmin));
-	const bool hit = tn <= tf * 1.000001f && ref != SRT_BVH_NONE;
-	t_out = hit ? tn : __builtin_inff();
-	ref_out = hit ? ref : SRT_BVH_NONE;
+// one plane quarter of a block: the hierarchy's base stays in SGPRs, the lane supplies a 32-bit byte offset
+__device__ __forceinline__ float4 bvh_quarter(const float4 *__restrict__ blocks, uint32_t byte_offset, uint32_t imm) {
+	return *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(blocks) + (size_t)byte_offset + imm);
 }
 
-__device__ __forceinline__ void bvh_order2(float &ta, uint32_t &ra, float &tb, uint32_t &rb) {
-	const bool swap = tb < ta;
-	const float t0 = swap ? tb : ta, t1 = swap ? ta : tb;
-	const uint32_t r0 = swap ? rb : ra, r1 = swap ? ra : rb;
-	ta = t0, tb = t1, ra = r0, rb = r1;
+// index inside its model of the triangle in record rec = (leaf block << 2) | slot
+__device__ __forceinline__ uint32_t bvh_tri_in_model(const float4 *__restrict__ blocks, uint32_t rec) {
+	return reinterpret_cast<const uint32_t *>(blocks)[(size_t)(rec >> 2) * 32u + SRT_BVH_LEAF_J + (rec & 3u)];
 }
 
+// Entry distance of one child as a sort key. near / far: the child's planes the ray meets first / last on each axis (picked
+// by the fetch). The distances are those of round 3's min / max form bit for bit: (lo - o) * inv <= (hi - o) * inv exactly when
+// inv >= 0, rounding is monotone.
+__device__ __forceinline__ uint32_t bvh_child_key(float nx, float fx, float ny, float fy, float nz, float fz, uint32_t tag, f3 org, f3 inv, float tmin) {
+	const float tnx = (nx - org.x) * inv.x, tfx = (fx - org.x) * inv.x;
+	const float tny = (ny - org.y) * inv.y, tfy = (fy - org.y) * inv.y;
+	const float tnz = (nz - org.z) * inv.z, tfz = (fz - org.z) * inv.z;
+	const float tn = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(tnx, tny), tnz), 0.0f);
+	const float tf = __builtin_fminf(__builtin_fminf(__builtin_fminf(tfx, tfy), tfz), tmin);
+	const bool hit = tn <= tf * 1.000001f; // (an empty slot's box: tn = +big, tf = -big. A distance of +inf cannot hold a hit either)
+	return ((hit ? f2u(tn) : SRT_BVH_KEY_INF) & ~SRT_BVH_TAG_MASK) | tag;
+}
+
+__device__ __forceinline__ void bvh_order2(uint32_t &a, uint32_t &b) {
+	const uint32_t lo = a < b ? a : b, hi = a < b ? b : a; // v_min_u32 / v_max_u32
+	a = lo, b = hi;
+}
+
+#ifndef SRT_BVH_PUSH_FORM
+#define SRT_BVH_PUSH_FORM 1 // 0: three unconditional stores, the idle ones into a spare slot: 37.7 / 37.8 ms against 34.7 / 33.9 -- the walk is bound by what it sends through the vector memory pipe
+#endif
 template <bool COUNT_TRIS>
 __device__ __forceinline__ void walk_bvh(const float4 *__restrict__ blocks, BvhStackEntry *__restrict__ stack, uint32_t root, f3 org, f3 dir, int idx,
-                                         float &tmin, int &best, uint32_t &best_rec, uint32_t &best_j, uint32_t &n_tri, uint32_t &n_tri_u SRT_RC_PARAM) {
+                                         float &tmin, int &best, uint32_t &best_rec, uint32_t &n_tri, uint32_t &n_tri_u SRT_RC_PARAM) {
 	// 1/d, or +-2^100 where |d| < 2^-100: (lo - o) * inv stays finite (no 0 * inf = NaN), and keeps its sign
 	f3 inv;
 	inv.x = dm_fabs(dir.x) >= 0x1p-100f ? 1.0f / dir.x : __builtin_copysignf(0x1p100f, dir.x);
 	inv.y = dm_fabs(dir.y) >= 0x1p-100f ? 1.0f / dir.y : __builtin_copysignf(0x1p100f, dir.y);
 	inv.z = dm_fabs(dir.z) >= 0x1p-100f ? 1.0f / dir.z : __builtin_copysignf(0x1p100f, dir.z);
-	uint32_t cur = root;
-	uint32_t top_ref = SRT_BVH_NONE; // the youngest waiting entry; stack[0 .. sp) the older ones
-	float top_t = 0.0f;
+	// which quarter of an axis's pair holds the near planes: lo (the first) for a positive direction, hi (16 bytes on) for a negative one
+	const uint32_t sx = inv.x < 0.0f ? 16u : 0u, sy = inv.y < 0.0f ? 16u : 0u, sz = inv.z < 0.0f ? 16u : 0u;
+	uint32_t cur = root == SRT_BVH_NONE ? SRT_BVH_NONE : (root & SRT_BVH_INDEX_MASK);
+	uint32_t cur_key = SRT_BVH_TAG(root, 0u);
+	// The youngest waiting entry lives in registers, stack[0 .. sp) holds the older ones. Under them all lies a sentinel that
+	// always passes the distance test and leads to block NONE: popping it ends the walk, so no pop asks whether the stack is empty.
+	uint32_t top_key = 0u, top_first = SRT_BVH_NONE;
 	uint32_t sp = 0u;
+	stack[0].key = 0u, stack[0].first = SRT_BVH_NONE; // (what a pop of the sentinel itself reads back into the registers)
 	while (cur != SRT_BVH_NONE) {
 		SRT_REGION(EXTEND_BVH_STEP);
-		const float4 *__restrict__ b = blocks + 8u * (size_t)(cur & SRT_BVH_INDEX_MASK);
-		// all eight quarters, whatever the block holds: loads predicated on what a lane will look at (7 of an inner block,
-		// 3 / 5 / 8 of a leaf) were 25 % slower, the clause of eight unconditional loads is what keeps them in flight together
-		const float4 q0 = b[0], q1 = b[1], q2 = b[2], q3 = b[3], q4 = b[4], q5 = b[5], q6 = b[6], q7 = b[7];
-		uint32_t next = SRT_BVH_NONE;
-		if (cur & SRT_BVH_LEAF_BIT) {
-			const uint32_t cnt = (cur >> 28) & 3u, rec0 = (cur & SRT_BVH_INDEX_MASK) << 2;
+		// Seven quarters, whatever the block holds (predicated loads were 25 % slower, and what a vector load costs the walk it
+		// costs per instruction, whatever its width and however few lanes want it: profiles/r04_bvh_vmem_probe.md).
+		// A leaf's quarters come in order; an inner block's near plane first on each axis.
+		const bool leaf = (cur_key & SRT_BVH_TAG_LEAF) != 0u;
+		const uint32_t pick = leaf ? 0u : ~0u, at = cur << 7;
+		const uint32_t ax = at | (sx & pick), ay = at | (sy & pick), az = at | (sz & pick);
+		const float4 q0 = bvh_quarter(blocks, ax, 0u), q1 = bvh_quarter(blocks, ax ^ 16u, 0u);
+		const float4 q2 = bvh_quarter(blocks, ay, 32u), q3 = bvh_quarter(blocks, ay ^ 16u, 32u);
+		const float4 q4 = bvh_quarter(blocks, az, 64u), q5 = bvh_quarter(blocks, az ^ 16u, 64u);
+		const float4 q6 = bvh_quarter(blocks, at, 96u); // (the last quarter of a leaf holds what only an accepted hit needs: SRT_BVH_LEAF_J)
+#ifdef SRT_BVH_PROBE // what one more vector load per step costs (profiles/r04_bvh_vmem_probe.md): 1 = every lane, the block's own line, 16 bytes; 2 = one lane only; 3 = every lane, the neighbouring line; 4 / 5 / 6 = every lane, 8 / 12 / 4 bytes
+		{
+			const uint32_t pa = SRT_BVH_PROBE == 3 ? (at ^ 128u) : at;
+			if (SRT_BVH_PROBE != 2 || (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) == __builtin_ctzll(__builtin_amdgcn_ballot_w64(true))) {
+				typedef float probe_v4f __attribute__((ext_vector_type(SRT_BVH_PROBE == 4 ? 2 : SRT_BVH_PROBE == 5 ? 3 : SRT_BVH_PROBE == 6 ? 1 : 4)));
+				const probe_v4f e = *reinterpret_cast<const volatile probe_v4f *>(reinterpret_cast<const char *>(blocks) + (size_t)pa + 20u);
+				asm volatile("" ::"v"(e[0]));
+			}
+		}
+#endif
+		bool pending = true; // nothing to enter from here: take the youngest waiting child
+		uint32_t next = SRT_BVH_NONE, next_key = 0u;
+		if (leaf) {
+			const uint32_t cnt = (cur_key >> 2) & 3u, rec0 = cur << 2;
 			if (COUNT_TRIS) n_tri += cnt;
-			auto tri = [&](float v0x, float v0y, float v0z, float e1x, float e1y, float e1z, float e2x, float e2y, float e2z, float jf, uint32_t k) {
+			auto tri = [&](float v0x, float v0y, float v0z, float e1x, float e1y, float e1z, float e2x, float e2y, float e2z, uint32_t k) {
 				float t = 0.0f;
 				if (moller_trumbore<COUNT_TRIS>(v0x, v0y, v0z, e1x, e1y, e1z, e2x, e2y, e2z, org, dir, true, t, n_tri_u SRT_RC_ARG)) {
-					const uint32_t j = f2u(jf);
-					if (t < tmin || (t == tmin && best == idx && j < best_j)) {
+					bool wins = t < tmin;
+					if (t == tmin && best == idx) // the reference keeps the FIRST triangle of equal t: the indices inside the model decide (fetched only here)
+						wins = bvh_tri_in_model(blocks, rec0 + k) < bvh_tri_in_model(blocks, best_rec);
+					if (wins) {
 						tmin = t;
 						best = idx;
 						best_rec = rec0 + k;
-						best_j = j;
 					}
 				}
 			};
-			tri(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, 0u);
-			if (cnt > 1u) tri(q2.z, q2.w, q3.x, q3.y, q3.z, q3.w, q4.x, q4.y, q4.z, q4.w, 1u);
-			if (cnt > 2u) tri(q5.x, q5.y, q5.z, q5.w, q6.x, q6.y, q6.z, q6.w, q7.x, q7.y, 2u);
+			tri(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, 0u);
+			if (cnt > 1u) tri(q2.y, q2.z, q2.w, q3.x, q3.y, q3.z, q3.w, q4.x, q4.y, 1u);
+			if (cnt > 2u) tri(q4.z, q4.w, q5.x, q5.y, q5.z, q5.w, q6.x, q6.y, q6.z, 2u);
 		} else {
-			float t0, t1, t2, t3;
-			uint32_t r0, r1, r2, r3;
-			bvh_child(q0.x, q1.x, q2.x, q3.x, q4.x, q5.x, f2u(q6.x), org, inv, tmin, t0, r0);
-			bvh_child(q0.y, q1.y, q2.y, q3.y, q4.y, q5.y, f2u(q6.y), org, inv, tmin, t1, r1);
-			bvh_child(q0.z, q1.z, q2.z, q3.z, q4.z, q5.z, f2u(q6.z), org, inv, tmin, t2, r2);
-			bvh_child(q0.w, q1.w, q2.w, q3.w, q4.w, q5.w, f2u(q6.w), org, inv, tmin, t3, r3);
-			bvh_order2(t0, r0, t1, r1);
-			bvh_order2(t2, r2, t3, r3);
-			bvh_order2(t0, r0, t2, r2);
-			bvh_order2(t1, r1, t3, r3);
-			bvh_order2(t1, r1, t2, r2); // nearest first; misses (t = inf, ref = NONE) last
-			next = r0;
-			// the others wait, farthest pushed first
-			auto push = [&](uint32_t r, float t) {
-				if (r != SRT_BVH_NONE) {
-					if (top_ref != SRT_BVH_NONE) {
-						stack[sp].ref = top_ref, stack[sp].t = top_t;
-						sp++;
-					}
-					top_ref = r, top_t = t;
-				}
-			};
-			push(r3, t3);
-			push(r2, t2);
-			push(r1, t1);
+			const uint32_t tags = f2u(q6.x), first = f2u(q6.y);
+			uint32_t k0 = bvh_child_key(q0.x, q1.x, q2.x, q3.x, q4.x, q5.x, tags & 255u, org, inv, tmin);
+			uint32_t k1 = bvh_child_key(q0.y, q1.y, q2.y, q3.y, q4.y, q5.y, (tags >> 8) & 255u, org, inv, tmin);
+			uint32_t k2 = bvh_child_key(q0.z, q1.z, q2.z, q3.z, q4.z, q5.z, (tags >> 16) & 255u, org, inv, tmin);
+			uint32_t k3 = bvh_child_key(q0.w, q1.w, q2.w, q3.w, q4.w, q5.w, tags >> 24, org, inv, tmin);
+			bvh_order2(k0, k1);
+			bvh_order2(k2, k3);
+			bvh_order2(k0, k2);
+			bvh_order2(k1, k3);
+			bvh_order2(k1, k2); // nearest first; the children that are not entered (keys >= KEY_INF) last
+			// k0 is entered now. The n others wait, farthest deepest: the registers' entry goes to memory and k1 takes its place,
+			// k3 and k2 go between them. Three unconditional stores, the ones with nothing to say into a slot nobody reads.
+			const uint32_t w1 = k1 < SRT_BVH_KEY_INF ? 1u : 0u, w2 = k2 < SRT_BVH_KEY_INF ? 1u : 0u, w3 = k3 < SRT_BVH_KEY_INF ? 1u : 0u;
+			const uint32_t n = w1 + w2 + w3;
+#if SRT_BVH_PUSH_FORM == 0
+			const uint32_t i0 = w1 ? sp : SRT_BVH_STACK_CAP, i3 = w3 ? sp + 1u : SRT_BVH_STACK_CAP, i2 = w2 ? sp + n - 1u : SRT_BVH_STACK_CAP;
+			stack[i0].key = top_key, stack[i0].first = top_first;
+			stack[i3].key = k3, stack[i3].first = first;
+			stack[i2].key = k2, stack[i2].first = first;
+#else
+			if (w1) stack[sp].key = top_key, stack[sp].first = top_first;
+			if (w3) stack[sp + 1u].key = k3, stack[sp + 1u].first = first;
+			if (w2) stack[sp + n - 1u].key = k2, stack[sp + n - 1u].first = first;
+#endif
+			top_key = w1 ? k1 : top_key, top_first = w1 ? first : top_first;
+			sp += n;
+			if (k0 < SRT_BVH_KEY_INF) next = first + (k0 & 3u), next_key = k0, pending = false;
 		}
-		// nothing nearer to enter: the youngest waiting child that the closest hit so far has not put out of reach
-		while (next == SRT_BVH_NONE && top_ref != SRT_BVH_NONE) {
-			if (top_t <= tmin * 1.000001f) next = top_ref;
-			if (sp > 0u) {
-				sp--;
-				top_ref = stack[sp].ref, top_t = stack[sp].t;
-			} else {
-				top_ref = SRT_BVH_NONE;
-			}
+		// the youngest waiting child that the closest hit so far has not put out of reach (its distance was rounded down: compare
+		// against the limit's bits with the tag bits set)
+		const uint32_t reach = f2u(tmin * 1.000001f) | SRT_BVH_TAG_MASK;
+		while (pending) {
+			if (top_key <= reach) next = top_first + (top_key & 3u), next_key = top_key, pending = false;
+			sp = sp > 0u ? sp - 1u : 0u;
+			top_key = stack[sp].key, top_first = stack[sp].first;
 		}
-		cur = next;
+		cur = next, cur_key = next_key;
 	}
 }
 
@@ -1181,9 +1216,8 @@ __global__ __launch_bounds__(64, USE_BVH ? SRT_TRACE_WAVES_PER_SIMD_BVH : HAS_MO
 	int bounce = 0;
 	int best = -1;
 	uint32_t best_tri = 0; // index inside the model; with a BVH: (leaf block << 2) | slot
-	BvhStackEntry bvh_stack[USE_BVH ? SRT_BVH_STACK_CAP : 1]; // per lane, in scratch memory (walk_bvh)
+	BvhStackEntry bvh_stack[USE_BVH ? SRT_BVH_STACK_CAP + 1 : 1]; // per lane, in scratch memory (walk_bvh)
 	const float4 *__restrict__ bvh_blocks = reinterpret_cast<const float4 *>(p.bvh_blocks);
-	uint32_t best_j = 0;   // BVH only: index inside the model
 	unsigned long long actm = 0ull; // (wave-uniform) the lanes that hold a ray awaiting closest_intersection
 	unsigned long long resm = 0ull; // (wave-uniform) SUSPEND: of those, the rays taken back from a scan stack or the pool, which scan the model of their block `pos` now
 	float tmin = DM_INF_F; // closest hit so far of the ray under way (kept across a suspension)
@@ -1229,7 +1263,7 @@ __global__ __launch_bounds__(64, USE_BVH ? SRT_TRACE_WAVES_PER_SIMD_BVH : HAS_MO
 						if (!SUSPEND || !resumed) {
 							tmin = DM_INF_F;
 							best = -1;
-							best_tri = 0, best_j = 0;
+							best_tri = 0;
 							pos = 0;
 						}
 						bool part = true;       // SUSPEND: false once the ray has gone to the scan queue
@@ -1292,7 +1326,6 @@ __global__ __launch_bounds__(64, USE_BVH ? SRT_TRACE_WAVES_PER_SIMD_BVH : HAS_MO
 										sq[12 * SQ + e] = dm_u2f(seed), sq[13 * SQ + e] = dm_u2f((uint32_t)bounce), sq[14 * SQ + e] = dm_u2f(item);
 										sq[15 * SQ + e] = tmin, sq[16 * SQ + e] = dm_u2f((uint32_t)best), sq[17 * SQ + e] = dm_u2f(best_tri);
 										sq[18 * SQ + e] = dm_u2f(bidx);
-										if (USE_BVH) sq[19 * SQ + e] = dm_u2f(best_j);
 										part = false;
 										susp = 1u + sid;
 									}
@@ -1311,7 +1344,7 @@ __global__ __launch_bounds__(64, USE_BVH ? SRT_TRACE_WAVES_PER_SIMD_BVH : HAS_MO
 							}
 							if (scan0) {
 								if (USE_BVH) {
-									walk_bvh<COUNT_TRIS>(bvh_blocks, bvh_stack, f2u(b.v[3]), org, dir, base, tmin, best, best_tri, best_j, n_tri, n_tri_u SRT_RC_ARG);
+									walk_bvh<COUNT_TRIS>(bvh_blocks, bvh_stack, f2u(b.v[3]), org, dir, base, tmin, best, best_tri, n_tri, n_tri_u SRT_RC_ARG);
 								} else {
 									if (COUNT_TRIS) n_tri += f2u(b.v[7]);
 									test_triangles<COUNT_TRIS>(wtris, f2u(b.v[3]), f2u(b.v[7]), org, dir, base, tmin, best, best_tri, n_tri_u SRT_RC_ARG);
@@ -1319,7 +1352,7 @@ __global__ __launch_bounds__(64, USE_BVH ? SRT_TRACE_WAVES_PER_SIMD_BVH : HAS_MO
 							}
 							if (((code >> 2) & 7u) > 1u && on && test_aabb(b.v[8], b.v[9], b.v[10], b.v[12], b.v[13], b.v[14], org, inv, tmin)) {
 								if (USE_BVH) {
-									walk_bvh<COUNT_TRIS>(bvh_blocks, bvh_stack, f2u(b.v[11]), org, dir, base + 1, tmin, best, best_tri, best_j, n_tri, n_tri_u SRT_RC_ARG);
+									walk_bvh<COUNT_TRIS>(bvh_blocks, bvh_stack, f2u(b.v[11]), org, dir, base + 1, tmin, best, best_tri, n_tri, n_tri_u SRT_RC_ARG);
 								} else {
 									if (COUNT_TRIS) n_tri += f2u(b.v[15]);
 									test_triangles<COUNT_TRIS>(wtris, f2u(b.v[11]), f2u(b.v[15]), org, dir, base + 1, tmin, best, best_tri, n_tri_u SRT_RC_ARG);
@@ -1475,7 +1508,6 @@ __global__ __launch_bounds__(64, USE_BVH ? SRT_TRACE_WAVES_PER_SIMD_BVH : HAS_MO
 					bounce = (int)dm_f2u(hq[14 * HQ + e]);
 					item = dm_f2u(hq[15 * HQ + e]);
 					if (HAS_MODELS) best_tri = dm_f2u(hq[16 * HQ + e]);
-					if (USE_BVH) best_j = dm_f2u(hq[17 * HQ + e]);
 				}
 				asm volatile("" ::: "memory");
 				hq_head += n_pop;
@@ -1523,7 +1555,7 @@ __global__ __launch_bounds__(64, USE_BVH ? SRT_TRACE_WAVES_PER_SIMD_BVH : HAS_MO
 					const srt_model *__restrict__ m = &p.shapes[best].shape.model;
 					const float *__restrict__ w = USE_BVH ? p.bvh_blocks + (size_t)(best_tri >> 2) * 32u + (best_tri & 3u) * SRT_BVH_TRI_FLOATS
 					                                      : wtris + (size_t)(first_wtri + best_tri) * SRT_WTRI_FLOATS;
-					const uint32_t tri_in_model = USE_BVH ? best_j : best_tri;
+					const uint32_t tri_in_model = USE_BVH ? bvh_tri_in_model(reinterpret_cast<const float4 *>(p.bvh_blocks), best_tri) : best_tri;
 					f3 v0 = mk(w[0], w[1], w[2]);
 					f3 e1 = mk(w[3], w[4], w[5]);
 					f3 e2 = mk(w[6], w[7], w[8]);
@@ -1640,7 +1672,6 @@ __global__ __launch_bounds__(64, USE_BVH ? SRT_TRACE_WAVES_PER_SIMD_BVH : HAS_MO
 				hq[14 * HQ + e] = dm_u2f((uint32_t)bounce);
 				hq[15 * HQ + e] = dm_u2f(item);
 				if (HAS_MODELS) hq[16 * HQ + e] = dm_u2f(best_tri);
-				if (USE_BVH) hq[17 * HQ + e] = dm_u2f(best_j);
 			}
 			asm volatile("" ::: "memory");
 			hq_count += n_hit;
@@ -1772,7 +1803,6 @@ __global__ __launch_bounds__(64, USE_BVH ? SRT_TRACE_WAVES_PER_SIMD_BVH : HAS_MO
 						seed = dm_f2u(ld(src + 12 * 64)), bounce = (int)dm_f2u(ld(src + 13 * 64)), item = dm_f2u(ld(src + 14 * 64));
 						tmin = ld(src + 15 * 64), best = (int)dm_f2u(ld(src + 16 * 64)), best_tri = dm_f2u(ld(src + 17 * 64));
 						pos = dm_f2u(ld(src + 18 * 64));
-						if (USE_BVH) best_j = dm_f2u(ld(src + 19 * 64));
 					}
 					asm volatile("" ::: "memory");
 					resm = actm;
@@ -1813,7 +1843,6 @@ __global__ __launch_bounds__(64, USE_BVH ? SRT_TRACE_WAVES_PER_SIMD_BVH : HAS_MO
 					seed = dm_f2u(ld(sq + 12 * SQ + e)), bounce = (int)dm_f2u(ld(sq + 13 * SQ + e)), item = dm_f2u(ld(sq + 14 * SQ + e));
 					tmin = ld(sq + 15 * SQ + e), best = (int)dm_f2u(ld(sq + 16 * SQ + e)), best_tri = dm_f2u(ld(sq + 17 * SQ + e));
 					pos = dm_f2u(ld(sq + 18 * SQ + e));
-					if (USE_BVH) best_j = dm_f2u(ld(sq + 19 * SQ + e));
 				}
 				asm volatile("" ::: "memory");
 				resm = actm;
@@ -2106,7 +2135,7 @@ __global__ __launch_bounds__(256) void srt_prepass_kernel(const PrepassParams p)
 		w[0] = p0.x, w[1] = p0.y, w[2] = p0.z;
 		w[3] = e1.x, w[4] = e1.y, w[5] = e1.z;
 		w[6] = e2.x, w[7] = e2.y, w[8] = e2.z;
-		if (p.order) w[9] = dm_u2f(j);
+		if (p.order) p.wtris[(size_t)(p.dest[base + s] >> 2) * 32u + SRT_BVH_LEAF_J + (p.dest[base + s] & 3u)] = dm_u2f(j);
 	}
 }
 
@@ -2267,8 +2296,8 @@ int srt_bvh_suspends(void) { return SRT_BVH_SUSPEND; }
 int srt_sub_job_items(int has_models, int use_bvh) { return !has_models ? SRT_SUB_PLAIN : use_bvh ? SRT_SUB_BVH : SRT_SUB_MODELS; }
 
 int srt_trace_lds_floats(int has_models, int use_bvh) {
-	// the sky ring (10 fields), the hit queue (16..18 fields)
-	int n = 10 * SRT_RING_CAP + (has_models ? (use_bvh ? 18 * SRT_HQ_CAP_BVH : 17 * SRT_HQ_CAP_MODELS) : 16 * SRT_HQ_CAP);
+	// the sky ring (10 fields), the hit queue (16..17 fields)
+	int n = 10 * SRT_RING_CAP + (has_models ? (use_bvh ? 17 * SRT_HQ_CAP_BVH : 17 * SRT_HQ_CAP_MODELS) : 16 * SRT_HQ_CAP);
 #ifdef SRT_REGION_COUNT
 	n += 2 * SRT_REGION_MAX; // (waves, lanes) per region
 #endif

@@ -268,10 +268,9 @@ struct BvhBuilder {
 		std::vector<uint32_t> dest;
 		uint32_t root = SRT_BVH_NONE, need = 0;
 	};
-	static uint32_t fold_node(const std::vector<BvhNode> &c, uint32_t ci, bool balanced, Wide &w, uint32_t &need) {
+	// fills block `self` (already allocated) from node ci; returns the reference to it
+	static uint32_t fold_node(const std::vector<BvhNode> &c, uint32_t ci, uint32_t self, bool balanced, Wide &w, uint32_t &need) {
 		const BvhNode &nd = c[ci];
-		const uint32_t self = (uint32_t)(w.blocks.size() / 32);
-		w.blocks.resize(w.blocks.size() + 32, 0u);
 		if (nd.leaf) {
 			const uint32_t first = nd.leaf & 0x0fffffffu, cnt = nd.leaf >> 28;
 			for (uint32_t k = 0; k < cnt; k++) w.dest[first + k] = (self << 2) | k;
@@ -304,10 +303,21 @@ struct BvhBuilder {
 				kids[nk++] = c[o + 1u].skip;
 			}
 		}
+		// the children's blocks lie side by side: the walk finds child k at first + k
+		const uint32_t first = (uint32_t)(w.blocks.size() / 32);
+		w.blocks.resize(w.blocks.size() + 32 * (size_t)nk, 0u);
 		uint32_t deepest = 0;
-		for (uint32_t k = 0; k < nk; k++) {
+		uint32_t tags = 0;
+		for (uint32_t k = 0; k < 4; k++) {
+			const float fmax = FLT_MAX, fmin = -FLT_MAX;
+			if (k >= nk) { // an empty slot: a box no ray passes (lo > hi), whatever its direction's signs
+				uint32_t *blk = w.blocks.data() + 32 * (size_t)self;
+				for (int a = 0; a < 3; a++) memcpy(&blk[8 * a + k], &fmax, 4), memcpy(&blk[8 * a + 4 + k], &fmin, 4);
+				tags |= k << (8 * k);
+				continue;
+			}
 			uint32_t sub = 0;
-			const uint32_t ref = fold_node(c, kids[k], balanced, w, sub); // may grow w.blocks: index, do not keep pointers
+			const uint32_t ref = fold_node(c, kids[k], first + k, balanced, w, sub); // may grow w.blocks: index, do not keep pointers
 			if (sub > deepest) deepest = sub;
 			uint32_t *blk = w.blocks.data() + 32 * (size_t)self;
 			const BvhNode &kid = c[kids[k]];
@@ -315,19 +325,21 @@ struct BvhBuilder {
 				memcpy(&blk[8 * a + k], &kid.lo[a], 4);
 				memcpy(&blk[8 * a + 4 + k], &kid.hi[a], 4);
 			}
-			blk[24 + k] = ref;
+			tags |= SRT_BVH_TAG(ref, k) << (8 * k);
 		}
-		for (uint32_t k = nk; k < 4; k++) w.blocks[32 * (size_t)self + 24 + k] = SRT_BVH_NONE;
+		w.blocks[32 * (size_t)self + 24] = tags;
+		w.blocks[32 * (size_t)self + 25] = first;
+		w.blocks[32 * (size_t)self + 26] = nk;
 		need = deepest + (nk - 1u);
-		return ref_of_inner(self);
+		return self;
 	}
-	static uint32_t ref_of_inner(uint32_t block) { return block; }
 	static void fold_wide(const std::vector<BvhNode> &c, uint32_t records, bool balanced, Wide &w) {
 		w.blocks.clear(), w.inner.clear();
 		w.dest.assign(records, 0u);
 		w.root = SRT_BVH_NONE, w.need = 0;
 		if (c.empty()) return;
-		w.root = fold_node(c, 0u, balanced, w, w.need);
+		w.blocks.resize(32, 0u);
+		w.root = fold_node(c, 0u, 0u, balanced, w, w.need);
 	}
 
 	// Appends the model's nodes and triangle order; returns the root's index.
@@ -768,14 +780,10 @@ static int prepare_scene(srt_tracer *t, ScenePrep &sp, const srt_shape *shapes, 
 				// model lands in the scene's arrays.
 				const uint32_t b0 = (uint32_t)(bvh_blocks.size() / 32), r0 = (uint32_t)total_wtris;
 				const BvhBuilder::Wide &wd = ent->wide;
-				if ((uint64_t)b0 + wd.blocks.size() / 32 > SRT_BVH_INDEX_MASK) return fail(t, SRT_ERR_INVALID, "srt_update_scene: too many BVH blocks");
+				if ((uint64_t)b0 + wd.blocks.size() / 32 > SRT_BVH_INDEX_MAX) return fail(t, SRT_ERR_INVALID, "srt_update_scene: too many BVH blocks");
 				if (wd.need > SRT_BVH_STACK_CAP) return fail(t, SRT_ERR_INVALID, "srt_update_scene: BVH deeper than the walk's stack"); // unreachable below 2^28 triangles
 				bvh_blocks.insert(bvh_blocks.end(), wd.blocks.begin(), wd.blocks.end());
-				for (uint32_t ib : wd.inner)
-					for (int k = 0; k < 4; k++) {
-						uint32_t &ref = bvh_blocks[32 * (size_t)(b0 + ib) + 24 + k];
-						if (ref != SRT_BVH_NONE) ref += b0;
-					}
+				for (uint32_t ib : wd.inner) bvh_blocks[32 * (size_t)(b0 + ib) + 25] += b0; // where the block's children lie
 				bvh_dest.resize(r0 + (size_t)m.num_triangles);
 				for (uint32_t r = 0; r < m.num_triangles; r++) bvh_dest[r0 + r] = wd.dest[r] + (b0 << 2);
 				bvh_canonical_nodes += ent->nodes.size();

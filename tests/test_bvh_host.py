@@ -10,6 +10,7 @@ import pytest
 from simple_raytracer_amd import records as R, scenes as S, tracer as T
 
 END = T.BVH_END
+FLT_MAX = np.finfo(np.float32).max
 LEAF_MAX = 3  # SRT_BVH_LEAF_MAX (csrc/device_types.h)
 
 
@@ -72,6 +73,9 @@ def check_wide(wide, nodes, order, n_tris):
     boxes = {(tuple(nd["lo"]), tuple(nd["hi"])) for nd in nodes}
     inner = leaves = 0
 
+    def ref_of(tag, idx):  # a child's tag + block index in the form of the root reference
+        return ((tag >> 4) << 31) | (((tag >> 2) & 3) << 28) | idx
+
     def need_of(ref):
         nonlocal inner, leaves
         idx = ref & T.BVH_INDEX_MASK
@@ -86,15 +90,16 @@ def check_wide(wide, nodes, order, n_tris):
             leaves += 1
             return 0
         inner += 1
-        refs = [int(r) for r in blocks[idx, 24:28]]
-        kids = [r for r in refs if r != T.BVH_NONE]
-        assert 2 <= len(kids) <= 4 and refs[:len(kids)] == kids, "children are packed to the front"
-        assert not blocks[idx, 28:].any()
-        for k in range(len(kids)):
+        tags, first, nk = [(int(blocks[idx, 24]) >> (8 * k)) & 255 for k in range(4)], int(blocks[idx, 25]), int(blocks[idx, 26])
+        assert 2 <= nk <= 4 and not blocks[idx, 27:].any() and first + nk <= len(blocks)
+        assert [t & 3 for t in tags] == [0, 1, 2, 3], "a tag carries its slot"
+        for k in range(nk):
             lo = tuple(fl[idx, [k, 8 + k, 16 + k]])
             hi = tuple(fl[idx, [4 + k, 12 + k, 20 + k]])
             assert (lo, hi) in boxes
-        return len(kids) - 1 + max(need_of(r) for r in kids)
+        for k in range(nk, 4):  # empty slots: a box nothing passes, children are packed to the front
+            assert (fl[idx, [k, 8 + k, 16 + k]] == FLT_MAX).all() and (fl[idx, [4 + k, 12 + k, 20 + k]] == -FLT_MAX).all() and tags[k] == k
+        return nk - 1 + max(need_of(ref_of(tags[k], first + k)) for k in range(nk))
 
     import sys
     sys.setrecursionlimit(10000)
@@ -107,40 +112,45 @@ def check_wide(wide, nodes, order, n_tris):
 
 def walk(wide, rec_of_slot, org, d):
     """The device's walk (csrc/kernels.hip walk_bvh) with tmin = inf, in float32; returns the tested records, the
-    blocks fetched and the deepest the stack got."""
+    blocks fetched and the deepest the stack got (waiting children, as the host's bound counts them)."""
     f = np.float32
     org, d = org.astype(f), d.astype(f)
     with np.errstate(all="ignore"):
         inv = np.where(np.abs(d) >= f(2.0 ** -100), f(1) / d, np.copysign(f(2.0 ** 100), d)).astype(f)
+    neg = inv < 0
     blocks = wide["blocks"]
     fl = blocks.view(np.float32)
     tested, steps, deepest = [], 0, 0
-    stack, cur = [], wide["root"]
-    while cur != T.BVH_NONE:
+    root = wide["root"]
+    stack = []  # (key, first)
+    cur = None if root == T.BVH_NONE else (root & T.BVH_INDEX_MASK, ((root >> 31) << 4) | (((root >> 28) & 3) << 2))
+    while cur is not None:
         steps += 1
-        idx = cur & T.BVH_INDEX_MASK
-        nxt = T.BVH_NONE
-        if cur & T.BVH_LEAF_BIT:
-            tested.extend(rec_of_slot[(idx << 2) | k] for k in range((cur >> 28) & 3))
+        idx, tag = cur
+        cur = None
+        if tag & 16:
+            tested.extend(rec_of_slot[(idx << 2) | k] for k in range((tag >> 2) & 3))
         else:
-            hits = []
+            first, keys = int(blocks[idx, 25]), []
             for k in range(4):
-                ref = int(blocks[idx, 24 + k])
                 lo, hi = fl[idx, [k, 8 + k, 16 + k]], fl[idx, [4 + k, 12 + k, 20 + k]]
+                near, far = np.where(neg, hi, lo), np.where(neg, lo, hi)  # what the lane's addresses pick
                 with np.errstate(all="ignore"):
-                    a1, a2 = (lo - org) * inv, (hi - org) * inv
-                tn = max(np.minimum(a1, a2).max(), f(0))
-                tf = np.maximum(a1, a2).min()
-                if tn <= tf * f(1.000001) and ref != T.BVH_NONE:
-                    hits.append((tn, ref))
-            hits.sort(key=lambda h: h[0])
-            if hits:
-                nxt = hits[0][1]
-                stack.extend(r for _, r in reversed(hits[1:]))
+                    tn = max(((near - org) * inv).max(), f(0))
+                    tf = ((far - org) * inv).min()
+                    hit = tn <= tf * f(1.000001)
+                bits = int(np.array([tn], f).view(np.uint32)[0]) if hit else 0x7F800000
+                keys.append((bits & ~31) | ((int(blocks[idx, 24]) >> (8 * k)) & 255))
+            keys.sort()
+            enter = [k for k in keys if k < 0x7F800000]
+            assert all(k & 3 < int(blocks[idx, 26]) for k in enter), "an empty slot was entered"
+            if enter:
+                cur = (first + (enter[0] & 3), enter[0])
+                stack.extend((k, first) for k in reversed(enter[1:]))
                 deepest = max(deepest, len(stack))
-        if nxt == T.BVH_NONE and stack:
-            nxt = stack.pop()
-        cur = nxt
+        if cur is None and stack:
+            key, first = stack.pop()
+            cur = (first + (key & 3), key)
     return tested, steps, deepest
 
 

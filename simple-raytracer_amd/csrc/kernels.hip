@@ -792,6 +792,11 @@ __device__ __forceinline__ void walk_bvh(const float4 *__restrict__ blocks, BvhS
 	stack[0].key = 0u, stack[0].first = SRT_BVH_NONE; // (what a pop of the sentinel itself reads back into the registers)
 	while (cur != SRT_BVH_NONE) {
 		SRT_REGION(EXTEND_BVH_STEP);
+		bool pending = true; // nothing to enter from here: take the youngest waiting child
+		uint32_t next = SRT_BVH_NONE, next_key = 0u;
+		bool inner = false;
+		uint32_t k0 = SRT_BVH_KEY_INF, k1 = SRT_BVH_KEY_INF, k2 = SRT_BVH_KEY_INF, k3 = SRT_BVH_KEY_INF, first = 0u;
+		{
 		// Seven quarters, whatever the block holds (predicated loads were 25 % slower, and what a vector load costs the walk it
 		// costs per instruction, whatever its width and however few lanes want it: profiles/r04_bvh_vmem_probe.md).
 		// A leaf's quarters come in order; an inner block's near plane first on each axis.
@@ -812,8 +817,6 @@ __device__ __forceinline__ void walk_bvh(const float4 *__restrict__ blocks, BvhS
 			}
 		}
 #endif
-		bool pending = true; // nothing to enter from here: take the youngest waiting child
-		uint32_t next = SRT_BVH_NONE, next_key = 0u;
 		if (leaf) {
 			const uint32_t cnt = (cur_key >> 2) & 3u, rec0 = cur << 2;
 			if (COUNT_TRIS) n_tri += cnt;
@@ -834,18 +837,23 @@ __device__ __forceinline__ void walk_bvh(const float4 *__restrict__ blocks, BvhS
 			if (cnt > 1u) tri(q2.y, q2.z, q2.w, q3.x, q3.y, q3.z, q3.w, q4.x, q4.y, 1u);
 			if (cnt > 2u) tri(q4.z, q4.w, q5.x, q5.y, q5.z, q5.w, q6.x, q6.y, q6.z, 2u);
 		} else {
-			const uint32_t tags = f2u(q6.x), first = f2u(q6.y);
-			uint32_t k0 = bvh_child_key(q0.x, q1.x, q2.x, q3.x, q4.x, q5.x, tags & 255u, org, inv, tmin);
-			uint32_t k1 = bvh_child_key(q0.y, q1.y, q2.y, q3.y, q4.y, q5.y, (tags >> 8) & 255u, org, inv, tmin);
-			uint32_t k2 = bvh_child_key(q0.z, q1.z, q2.z, q3.z, q4.z, q5.z, (tags >> 16) & 255u, org, inv, tmin);
-			uint32_t k3 = bvh_child_key(q0.w, q1.w, q2.w, q3.w, q4.w, q5.w, tags >> 24, org, inv, tmin);
+			const uint32_t tags = f2u(q6.x);
+			first = f2u(q6.y);
+			k0 = bvh_child_key(q0.x, q1.x, q2.x, q3.x, q4.x, q5.x, tags & 255u, org, inv, tmin);
+			k1 = bvh_child_key(q0.y, q1.y, q2.y, q3.y, q4.y, q5.y, (tags >> 8) & 255u, org, inv, tmin);
+			k2 = bvh_child_key(q0.z, q1.z, q2.z, q3.z, q4.z, q5.z, (tags >> 16) & 255u, org, inv, tmin);
+			k3 = bvh_child_key(q0.w, q1.w, q2.w, q3.w, q4.w, q5.w, tags >> 24, org, inv, tmin);
+			inner = true;
+		}
+		}
+		if (inner) {
 			bvh_order2(k0, k1);
 			bvh_order2(k2, k3);
 			bvh_order2(k0, k2);
 			bvh_order2(k1, k3);
 			bvh_order2(k1, k2); // nearest first; the children that are not entered (keys >= KEY_INF) last
 			// k0 is entered now. The n others wait, farthest deepest: the registers' entry goes to memory and k1 takes its place,
-			// k3 and k2 go between them. Three unconditional stores, the ones with nothing to say into a slot nobody reads.
+			// k3 and k2 go between them.
 			const uint32_t w1 = k1 < SRT_BVH_KEY_INF ? 1u : 0u, w2 = k2 < SRT_BVH_KEY_INF ? 1u : 0u, w3 = k3 < SRT_BVH_KEY_INF ? 1u : 0u;
 			const uint32_t n = w1 + w2 + w3;
 #if SRT_BVH_PUSH_FORM == 0

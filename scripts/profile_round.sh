@@ -7,11 +7,6 @@ TAG=$1
 R=$PWD
 OUT=$R/gpurun_out/profile_$TAG
 mkdir -p $OUT
-python bench.py --steps 5 --warmup 1 > $OUT/bench.json 2> $OUT/bench.err; echo "bench rc=$?"
-( cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-other-configs > $OUT/stats.log 2>&1 ); echo "stats rc=$?"
-cp $(find $OUT/stats -name "*kernel_stats.csv" | head -1) $OUT/bench_kernel_stats.csv
-scripts/pmc_cmd.sh ${TAG}_spp64 sq1,sq2,mix,flow,cache,grbm scripts/sched_probe.py spheres > $OUT/pmc_spp64.log 2>&1; echo "pmc rc=$?"
-cp gpurun_out/pmc_${TAG}_spp64/summary.json $OUT/pmc_spp64.json
 ( cd /tmp && export TMPDIR=/tmp && for c in FETCH_SIZE WRITE_SIZE; do rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/$c -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-other-configs > $OUT/$c.log 2>&1; echo "$c rc=$?"; done )
 python3 - <<PY
 import csv, glob, collections, json, hashlib
@@ -32,4 +27,10 @@ tj = {"kernels_hip_sha256": hashlib.sha256(open("$R/simple-raytracer_amd/csrc/ke
 json.dump(tj, open("$OUT/traffic.json", "w"), indent=1, sort_keys=True)
 print(open("$OUT/traffic.json").read())
 PY
+cp $OUT/traffic.json $R/profiles/traffic.json  # (on the box's copy of the tree: the bench line below carries the traffic of THIS kernel source)
+python bench.py --steps 5 --warmup 1 > $OUT/bench.json 2> $OUT/bench.err; echo "bench rc=$?"
+( cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-other-configs > $OUT/stats.log 2>&1 ); echo "stats rc=$?"
+cp $(find $OUT/stats -name "*kernel_stats.csv" | head -1) $OUT/bench_kernel_stats.csv
+scripts/pmc_cmd.sh ${TAG}_spp64 sq1,sq2,mix,flow,cache,grbm scripts/sched_probe.py spheres > $OUT/pmc_spp64.log 2>&1; echo "pmc rc=$?"
+cp gpurun_out/pmc_${TAG}_spp64/summary.json $OUT/pmc_spp64.json
 for f in $OUT/bench.json; do echo "$(basename $f): $(python3 -c "import json,sys; d=json.loads(open('$f').read().strip().splitlines()[-1]); print(d['value'], d['unit'], d['ms_per_step'], 'ms', d['roofline']['frac']); [print(' ', o) for o in d.get('other_configs', [])]")"; done

@@ -1107,6 +1107,8 @@ int srt_trace_fused(srt_tracer *t, const srt_render_data *options, uint8_t *fuse
 			const uint32_t cap_u = cap < 1.0 ? 1u : (cap > 1e9 ? 0xffffffffu : (uint32_t)cap);
 			if (cap_u < batch) batch = cap_u;
 		}
+		if (const char *env = dev_env("SRT_FORCE_BATCH")) // (development: sample batches smaller than the memory asks for)
+			if (atoi(env) > 0 && (uint32_t)atoi(env) < batch) batch = (uint32_t)atoi(env);
 		// several batches alternate between TWO radiance buffers (below): both must fit the budget
 		if (SRT_OVERLAP_BATCHES && batch < (uint32_t)ns && (size_t)batch * 2 > fit) batch = (uint32_t)(fit / 2 ? fit / 2 : 1);
 		if (batch > 4 && (batch & 3u)) batch &= ~3u; // keep the reduce kernel's 16-byte loads aligned

@@ -116,6 +116,32 @@ def test_bvh_mesh100k_against_the_oracle(T, sky, oracle):
     t.close()
 
 
+def test_deep_hierarchies_walk_with_a_full_stack(T, sky):
+    """Triangles whose sizes and spacing grow geometrically (tests/test_bvh_host.py: the SAH peels them off one at a time):
+    the walk with the most children waiting that a hierarchy may ask of the 64-entry stack, as the SAH builds it and in the
+    balanced form the library falls back to; grazing rays along the chain keep many of them waiting at once. Same canvas
+    bits as the array scan."""
+    n = 400
+    tris = np.zeros(n, R.TRIANGLE)
+    for i in range(n):
+        s, x = 1.02 ** i, 60.0 * (1.02 ** i)
+        z = 3.0 * np.sin(0.7 * i)  # (not coplanar: the model's own box must have a thickness for a ray to enter it)
+        tris[i] = R.flat_triangle((0, 0, 1), (x, 0, z), (x + s, 0, z), (x, s, z + 0.5 * s))
+    mats = S.sphere_scene()[2]
+    shapes = np.zeros(2, R.SHAPE)
+    shapes[0] = R.plane(0, (0, -3, 0), (0, 1, 0))
+    shapes[1] = R.model(1, tris, 0, n, R.scale_matrix((0.004, 0.004, 0.004)))
+    wide = T.bvh_wide_host(shapes[1], tris)
+    assert wide["stack_need"] >= 12  # a hierarchy that does make the stack deep
+    cam = R.mat_mul(R.translate((-2.0, 0.05, 0.4)), R.euler_yxz(-1.45, 0.0, 0.0))  # looking along the chain
+    rd = R.render_data(192, 108, 4, 10, camera_to_world=cam, time=2718)
+    (c0, k0, _), (c1, k1, i1) = _both(T, sky, shapes, tris, mats, rd)
+    assert i1["nodes"] > 0 and k1["watchdog"] == 0
+    assert bits_equal(c1, c0)
+    assert (k1["rays"], k1["sky"], k1["paths"]) == (k0["rays"], k0["sky"], k0["paths"])
+    assert 0 < k1["tri_tests"] < k0["tri_tests"]
+
+
 def test_equal_distance_hits_keep_array_order(T, sky):
     """Coincident triangles: the reference keeps the FIRST of equal t (strict <, render.cl:254-256).
     A model made of the same quad four times over, each copy with its own vertex normals, must

@@ -46,7 +46,7 @@
 	X(PROLOGUE) X(LOOP_HEAD) X(EXTEND_SETUP) X(EXTEND_GROUP) X(EXTEND_SUSPEND)                                                       \
 	X(EXTEND_SPHERES2_0) X(EXTEND_SPHERES2_1) X(EXTEND_SPHERES2_2) X(EXTEND_SPHERES4_0) X(EXTEND_SPHERES4_1) X(EXTEND_SPHERES4_2)   \
 	X(EXTEND_PLANES_0) X(EXTEND_PLANES_1) X(EXTEND_PLANES_2) X(EXTEND_MODEL_0) X(EXTEND_MODEL_1) X(EXTEND_MODEL_2)                   \
-	X(EXTEND_TRI_LOOP) X(EXTEND_TRI_EXACT) X(EXTEND_TRI_DIV) X(EXTEND_BVH_STEP) X(EXTEND_FINISH) X(SKY_PUSH) X(SKY_RESOLVE) X(SHADE_HEAD) X(SHADE_POP) X(SHADE_WINNER)   \
+	X(EXTEND_TRI_LOOP) X(EXTEND_TRI_EXACT) X(EXTEND_TRI_DIV) X(EXTEND_BVH_STEP) X(EXTEND_BVH_SPILL) X(EXTEND_BVH_PUSH2) X(EXTEND_BVH_PUSH3) X(EXTEND_BVH_POP) X(EXTEND_FINISH) X(SKY_PUSH) X(SKY_RESOLVE) X(SHADE_HEAD) X(SHADE_POP) X(SHADE_WINNER)   \
 	X(SHADE_MESH_NORMAL) X(SHADE_MATERIAL) X(SHADE_BOUNCE) X(SHADE_OPAQUE) X(SHADE_GLASS) X(SHADE_REFRACT) X(SHADE_TAIL) X(PARK)     \
 	X(HANDIN) X(HANDIN_ORPHAN) X(REFILL_HEAD) X(REFILL_SCANQ) X(REFILL_POOL) X(REFILL_UNPARK) X(REFILL_LOOP) X(REFILL_OPEN) X(REFILL_FLUSH) X(REFILL_CURSOR)         \
 	X(REFILL_TAKE) X(CAMERA) X(LOOP_TAIL) X(EPILOGUE)
@@ -722,15 +722,14 @@ __device__ __forceinline__ void test_triangles(const float *__restrict__ wtris, 
 
 // ---- BVH walk (opt-in; device_types.h "wide hierarchy") ------------------------------------
 // Per lane: rays of a wave are incoherent after the first bounce, so blocks come through per-lane
-// loads, and a walk is a chain of dependent fetches whose latency nothing else in the wave covers
-// (profiles/README.md: the binary, own-box, skip-linked form spent 64 % of its wave cycles in
-// s_waitcnt, VALU 12 % busy). Hence 128-byte blocks that one fetch (8 x 16 B in flight) brings in
-// whole: an inner block holds the boxes of FOUR children, a leaf block up to three triangles, so a
-// ray takes about a quarter of the dependent steps of a binary walk, and the hierarchy of a 10^5-
-// triangle model is 8.5 MB instead of the 21 MB of eight octant-ordered copies. Children are visited
-// nearest first by their entry distance; the others wait, with that distance, on a per-lane stack in
-// scratch memory whose top entry lives in registers (a pop never waits for memory unless the entry it
-// uncovers is culled as well).
+// loads. What binds the walk is the CU's vector memory pipe -- ONE address unit for its 20 waves, busy
+// three quarters of a launch; a load costs per instruction, whatever its width and however few lanes
+// execute it (profiles/r04_bvh_vmem_probe.md) -- so a step is built around as few loads as the data
+// allows: 128-byte blocks of which SEVEN quarters are fetched, an inner block with the boxes of FOUR
+// children (a ray takes about a quarter of the steps of a binary walk; the hierarchy of a 10^5-
+// triangle model is 8.5 MB), a leaf block with up to three triangles (27 dwords: the seven quarters).
+// Children are visited nearest first by their entry distance; the others wait, with that distance, on a
+// per-lane stack in scratch memory whose top entry lives in registers.
 // Same Moller-Trumbore as the array scan, so every accepted hit has the same t; what the walk must
 // guarantee is that the triangle the array-order scan would settle on is visited and wins:
 //  * boxes were padded on the host and the slab test errs towards "hit" (safe inverse for zero
@@ -862,9 +861,18 @@ __device__ __forceinline__ void walk_bvh(const float4 *__restrict__ blocks, BvhS
 			stack[i3].key = k3, stack[i3].first = first;
 			stack[i2].key = k2, stack[i2].first = first;
 #else
-			if (w1) stack[sp].key = top_key, stack[sp].first = top_first;
-			if (w3) stack[sp + 1u].key = k3, stack[sp + 1u].first = first;
-			if (w2) stack[sp + n - 1u].key = k2, stack[sp + n - 1u].first = first;
+			if (w1) {
+				SRT_REGION(EXTEND_BVH_SPILL);
+				stack[sp].key = top_key, stack[sp].first = top_first;
+			}
+			if (w3) {
+				SRT_REGION(EXTEND_BVH_PUSH3);
+				stack[sp + 1u].key = k3, stack[sp + 1u].first = first;
+			}
+			if (w2) {
+				SRT_REGION(EXTEND_BVH_PUSH2);
+				stack[sp + n - 1u].key = k2, stack[sp + n - 1u].first = first;
+			}
 #endif
 			top_key = w1 ? k1 : top_key, top_first = w1 ? first : top_first;
 			sp += n;
@@ -874,6 +882,7 @@ __device__ __forceinline__ void walk_bvh(const float4 *__restrict__ blocks, BvhS
 		// against the limit's bits with the tag bits set)
 		const uint32_t reach = f2u(tmin * 1.000001f) | SRT_BVH_TAG_MASK;
 		while (pending) {
+			SRT_REGION(EXTEND_BVH_POP);
 			if (top_key <= reach) next = top_first + (top_key & 3u), next_key = top_key, pending = false;
 			sp = sp > 0u ? sp - 1u : 0u;
 			top_key = stack[sp].key, top_first = stack[sp].first;

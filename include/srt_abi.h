@@ -103,8 +103,8 @@ int srt_bvh_build_host(const srt_shape *model, const srt_triangle *triangles, si
                        size_t nodes_cap, uint32_t *order_out, size_t order_cap, size_t *n_nodes);
 
 /* Host-only: the WIDE form of that hierarchy, the one the kernel walks (layout: csrc/device_types.h; block indices
- * relative to the model's first block; an inner block: dwords 0-23 the boxes of four children, 24 their tags, 25 the
- * index of child 0 -- siblings lie side by side --, 26 how many there are). blocks_out receives at most blocks_cap blocks
+ * relative to the model's first block; an inner block: dwords 0-2 the origin of its grid, 3 the grid's exponents and the
+ * number of children, 4-9 the children's boxes as bytes, 10 their tags, 11 the index of child 0 -- siblings lie side by side). blocks_out receives at most blocks_cap blocks
  * of 32 dwords (leaf blocks are zero here: the device writes their triangles), dest_out[r] = (leaf block << 2) | slot of record r (records as in
  * srt_bvh_build_host's order). *root = the root reference (0xffffffff for a model without triangles), *stack_need =
  * the most children a walk can have waiting at once (never above the kernel's stack of 64: a hierarchy that would

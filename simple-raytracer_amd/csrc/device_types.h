@@ -53,21 +53,21 @@ static_assert(sizeof(WinnerRec) == 32, "WinnerRec 32 B");
  * (srt_bvh_node, include/srt_types.h: the form that is cached, refitted and handed out by
  * srt_bvh_build_host) and folds it into the WIDE form the kernel walks: 128-byte blocks, one cache
  * line and one fetch each.
- *   inner block  dwords 0-3 lo.x of children 0..3, 4-7 hi.x, 8-11 lo.y, 12-15 hi.y, 16-19 lo.z,
- *                20-23 hi.z, 24 their tags (child k in byte k), 25 the block index of child 0 (the
- *                children's blocks lie side by side: child k is block first + k), 26 how many
- *                children there are, 27-31 zero. An empty slot holds a box no ray passes (lo =
- *                FLT_MAX, hi = -FLT_MAX).
- *                SoA so that one 16-byte quarter is one plane of all four children: a lane fetches
- *                the NEAR planes (lo where its direction is positive, hi where negative) and the FAR
- *                ones by address and needs no min / max to tell them apart.
+ *   inner block  48 bytes of the 128: the boxes of up to FOUR children as bytes on a power-of-two grid relative to the
+ *                block's origin. Dwords 0-2 the origin, 3 the grid's biased exponents (x | y << 8 | z << 16) and in its
+ *                top byte the number of children, 4-6 lo.x / lo.y / lo.z of children 0..3 (child k in byte k), 7-9
+ *                hi.x / hi.y / hi.z, 10 their tags (child k in byte k), 11 the block index of child 0 (the children's
+ *                blocks lie side by side: child k is block first + k). bound = fmaf(byte, 2^(e - 127), origin), rounded
+ *                outwards on the host and checked there in exactly this arithmetic, so the decoded box contains the
+ *                child's (padded) box of the binary hierarchy; the kernel forms bound - o as fmaf(byte, 2^e, origin - o).
+ *                Why bytes: a vector load costs the CU's address unit per lane that executes it, whatever its width;
+ *                inner lanes fetch three quarters instead of seven (float boxes: 24 dwords + tags + first).
  *   leaf block   up to three triangles of SRT_BVH_TRI_FLOATS dwords {v0, e1, e2} (values as in
  *                SRT_WTRI_FLOATS above), dwords 0-26; dwords 28-30 (SRT_BVH_LEAF_J) their indices j
  *                inside the model, for the reference's first-in-array-order tie rule and for the
  *                vertex normals; all written by srt_prepass_kernel; unused slots stay zero.
- *                A step of the walk fetches the first SEVEN quarters of a block, whatever it is: the
- *                indices are looked at only where a hit is accepted at exactly the distance of the
- *                closest one so far, and by the shading.
+ *                The lanes on a leaf fetch its first SEVEN quarters: the indices are looked at only where a hit
+ *                is accepted at exactly the distance of the closest one so far, and by the shading.
  *   tag          5 bits: bit 4 = the child is a leaf block, bits 2-3 = triangles in it, bits 0-1 =
  *                the child's slot k. The walk sorts the children it enters by ONE dword each, the
  *                entry distance's bits with the tag in place of the five lowest (distances are >= 0,
@@ -80,6 +80,7 @@ static_assert(sizeof(WinnerRec) == 32, "WinnerRec 32 B");
  * A lane keeps the children it still has to enter on a stack of SRT_BVH_STACK_CAP entries; the host
  * checks every hierarchy against that bound (srt_abi.hip fold_wide) and falls back to a balanced one. */
 typedef srt_bvh_node BvhNode; /* include/srt_types.h */
+#define SRT_BVH_FIRST_DWORD 11 /* where an inner block keeps the index of its child 0 */
 #define SRT_BVH_TRI_FLOATS 9
 #define SRT_BVH_LEAF_J 28 /* dword of a leaf block with the first triangle's index inside the model */
 #define SRT_BVH_NONE 0xffffffffu

@@ -724,10 +724,10 @@ __device__ __forceinline__ void test_triangles(const float *__restrict__ wtris, 
 // Per lane: rays of a wave are incoherent after the first bounce, so blocks come through per-lane
 // loads. What binds the walk is the CU's vector memory pipe -- ONE address unit for its 20 waves, busy
 // three quarters of a launch; a load costs per instruction, whatever its width and however few lanes
-// execute it (profiles/r04_bvh_vmem_probe.md) -- so a step is built around as few loads as the data
-// allows: 128-byte blocks of which SEVEN quarters are fetched, an inner block with the boxes of FOUR
-// children (a ray takes about a quarter of the steps of a binary walk; the hierarchy of a 10^5-
-// triangle model is 8.5 MB), a leaf block with up to three triangles (27 dwords: the seven quarters).
+// execute it (profiles/r04_bvh_vmem_probe.md; per lane that executes it: scripts/microbench/ta_rates.hip) -- so a step
+// is built around as few loads as the data allows: an inner block holds the boxes of FOUR children as bytes on a grid of
+// its own (48 bytes: three quarters, a ray takes about a quarter of the steps of a binary walk), a leaf block up to three
+// triangles (27 dwords: seven quarters, fetched by the lanes that stand on a leaf).
 // Children are visited nearest first by their entry distance; the others wait, with that distance, on a
 // per-lane stack in scratch memory whose top entry lives in registers.
 // Same Moller-Trumbore as the array scan, so every accepted hit has the same t; what the walk must
@@ -751,19 +751,6 @@ __device__ __forceinline__ uint32_t bvh_tri_in_model(const float4 *__restrict__ 
 	return reinterpret_cast<const uint32_t *>(blocks)[(size_t)(rec >> 2) * 32u + SRT_BVH_LEAF_J + (rec & 3u)];
 }
 
-// Entry distance of one child as a sort key. near / far: the child's planes the ray meets first / last on each axis (picked
-// by the fetch). The distances are those of round 3's min / max form bit for bit: (lo - o) * inv <= (hi - o) * inv exactly when
-// inv >= 0, rounding is monotone.
-__device__ __forceinline__ uint32_t bvh_child_key(float nx, float fx, float ny, float fy, float nz, float fz, uint32_t tag, f3 org, f3 inv, float tmin) {
-	const float tnx = (nx - org.x) * inv.x, tfx = (fx - org.x) * inv.x;
-	const float tny = (ny - org.y) * inv.y, tfy = (fy - org.y) * inv.y;
-	const float tnz = (nz - org.z) * inv.z, tfz = (fz - org.z) * inv.z;
-	const float tn = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(tnx, tny), tnz), 0.0f);
-	const float tf = __builtin_fminf(__builtin_fminf(__builtin_fminf(tfx, tfy), tfz), tmin);
-	const bool hit = tn <= tf * 1.000001f; // (an empty slot's box: tn = +big, tf = -big. A distance of +inf cannot hold a hit either)
-	return ((hit ? f2u(tn) : SRT_BVH_KEY_INF) & ~SRT_BVH_TAG_MASK) | tag;
-}
-
 __device__ __forceinline__ void bvh_order2(uint32_t &a, uint32_t &b) {
 	const uint32_t lo = a < b ? a : b, hi = a < b ? b : a; // v_min_u32 / v_max_u32
 	a = lo, b = hi;
@@ -780,8 +767,8 @@ __device__ __forceinline__ void walk_bvh(const float4 *__restrict__ blocks, BvhS
 	inv.x = dm_fabs(dir.x) >= 0x1p-100f ? 1.0f / dir.x : __builtin_copysignf(0x1p100f, dir.x);
 	inv.y = dm_fabs(dir.y) >= 0x1p-100f ? 1.0f / dir.y : __builtin_copysignf(0x1p100f, dir.y);
 	inv.z = dm_fabs(dir.z) >= 0x1p-100f ? 1.0f / dir.z : __builtin_copysignf(0x1p100f, dir.z);
-	// which quarter of an axis's pair holds the near planes: lo (the first) for a positive direction, hi (16 bytes on) for a negative one
-	const uint32_t sx = inv.x < 0.0f ? 16u : 0u, sy = inv.y < 0.0f ? 16u : 0u, sz = inv.z < 0.0f ? 16u : 0u;
+	// which planes of a box the ray meets first: lo for a positive direction, hi for a negative one
+	const bool sx = inv.x < 0.0f, sy = inv.y < 0.0f, sz = inv.z < 0.0f;
 	uint32_t cur = root == SRT_BVH_NONE ? SRT_BVH_NONE : (root & SRT_BVH_INDEX_MASK);
 	uint32_t cur_key = SRT_BVH_TAG(root, 0u);
 	// The youngest waiting entry lives in registers, stack[0 .. sp) holds the older ones. Under them all lies a sentinel that
@@ -796,27 +783,13 @@ __device__ __forceinline__ void walk_bvh(const float4 *__restrict__ blocks, BvhS
 		bool inner = false;
 		uint32_t k0 = SRT_BVH_KEY_INF, k1 = SRT_BVH_KEY_INF, k2 = SRT_BVH_KEY_INF, k3 = SRT_BVH_KEY_INF, first = 0u;
 		{
-		// Seven quarters, whatever the block holds (predicated loads were 25 % slower, and what a vector load costs the walk it
-		// costs per instruction, whatever its width and however few lanes want it: profiles/r04_bvh_vmem_probe.md).
-		// A leaf's quarters come in order; an inner block's near plane first on each axis.
+		// An inner block is 48 bytes: every lane fetches three quarters, the lanes that stand on a leaf the other four (what a
+		// load costs the CU's address unit it costs per lane that executes it: scripts/microbench/ta_rates.hip).
 		const bool leaf = (cur_key & SRT_BVH_TAG_LEAF) != 0u;
-		const uint32_t pick = leaf ? 0u : ~0u, at = cur << 7;
-		const uint32_t ax = at | (sx & pick), ay = at | (sy & pick), az = at | (sz & pick);
-		const float4 q0 = bvh_quarter(blocks, ax, 0u), q1 = bvh_quarter(blocks, ax ^ 16u, 0u);
-		const float4 q2 = bvh_quarter(blocks, ay, 32u), q3 = bvh_quarter(blocks, ay ^ 16u, 32u);
-		const float4 q4 = bvh_quarter(blocks, az, 64u), q5 = bvh_quarter(blocks, az ^ 16u, 64u);
-		const float4 q6 = bvh_quarter(blocks, at, 96u); // (the last quarter of a leaf holds what only an accepted hit needs: SRT_BVH_LEAF_J)
-#ifdef SRT_BVH_PROBE // what one more vector load per step costs (profiles/r04_bvh_vmem_probe.md): 1 = every lane, the block's own line, 16 bytes; 2 = one lane only; 3 = every lane, the neighbouring line; 4 / 5 / 6 = every lane, 8 / 12 / 4 bytes
-		{
-			const uint32_t pa = SRT_BVH_PROBE == 3 ? (at ^ 128u) : at;
-			if (SRT_BVH_PROBE != 2 || (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) == __builtin_ctzll(__builtin_amdgcn_ballot_w64(true))) {
-				typedef float probe_v4f __attribute__((ext_vector_type(SRT_BVH_PROBE == 4 ? 2 : SRT_BVH_PROBE == 5 ? 3 : SRT_BVH_PROBE == 6 ? 1 : 4)));
-				const probe_v4f e = *reinterpret_cast<const volatile probe_v4f *>(reinterpret_cast<const char *>(blocks) + (size_t)pa + 20u);
-				asm volatile("" ::"v"(e[0]));
-			}
-		}
-#endif
+		const uint32_t at = cur << 7;
+		const float4 q0 = bvh_quarter(blocks, at, 0u), q1 = bvh_quarter(blocks, at, 16u), q2 = bvh_quarter(blocks, at, 32u);
 		if (leaf) {
+			const float4 q3 = bvh_quarter(blocks, at, 48u), q4 = bvh_quarter(blocks, at, 64u), q5 = bvh_quarter(blocks, at, 80u), q6 = bvh_quarter(blocks, at, 96u);
 			const uint32_t cnt = (cur_key >> 2) & 3u, rec0 = cur << 2;
 			if (COUNT_TRIS) n_tri += cnt;
 			auto tri = [&](float v0x, float v0y, float v0z, float e1x, float e1y, float e1z, float e2x, float e2y, float e2z, uint32_t k) {
@@ -836,12 +809,29 @@ __device__ __forceinline__ void walk_bvh(const float4 *__restrict__ blocks, BvhS
 			if (cnt > 1u) tri(q2.y, q2.z, q2.w, q3.x, q3.y, q3.z, q3.w, q4.x, q4.y, 1u);
 			if (cnt > 2u) tri(q4.z, q4.w, q5.x, q5.y, q5.z, q5.w, q6.x, q6.y, q6.z, 2u);
 		} else {
-			const uint32_t tags = f2u(q6.x);
-			first = f2u(q6.y);
-			k0 = bvh_child_key(q0.x, q1.x, q2.x, q3.x, q4.x, q5.x, tags & 255u, org, inv, tmin);
-			k1 = bvh_child_key(q0.y, q1.y, q2.y, q3.y, q4.y, q5.y, (tags >> 8) & 255u, org, inv, tmin);
-			k2 = bvh_child_key(q0.z, q1.z, q2.z, q3.z, q4.z, q5.z, (tags >> 16) & 255u, org, inv, tmin);
-			k3 = bvh_child_key(q0.w, q1.w, q2.w, q3.w, q4.w, q5.w, tags >> 24, org, inv, tmin);
+			// four children, their boxes as bytes on a power-of-two grid relative to the block's origin: bound - o = fmaf(byte, 2^e,
+			// origin - o) (the host rounded the bytes outwards and checked them in fmaf(byte, 2^e, origin)); no product can be
+			// 0 * inf here: byte * 2^e is finite or, for the all-embracing boxes of hostile input, +inf
+			const uint32_t ex = f2u(q0.w), nk = ex >> 24;
+			const float gx = dm_u2f((ex & 255u) << 23), gy = dm_u2f(((ex >> 8) & 255u) << 23), gz = dm_u2f(((ex >> 16) & 255u) << 23);
+			const float cx = q0.x - org.x, cy = q0.y - org.y, cz = q0.z - org.z;
+			// the planes the ray meets first / last on each axis: lo / hi for a positive direction, hi / lo for a negative one
+			const uint32_t nxw = sx ? f2u(q1.w) : f2u(q1.x), fxw = sx ? f2u(q1.x) : f2u(q1.w);
+			const uint32_t nyw = sy ? f2u(q2.x) : f2u(q1.y), fyw = sy ? f2u(q1.y) : f2u(q2.x);
+			const uint32_t nzw = sz ? f2u(q2.y) : f2u(q1.z), fzw = sz ? f2u(q1.z) : f2u(q2.y);
+			const uint32_t tags = f2u(q2.z);
+			first = f2u(q2.w);
+			auto child = [&](int k, bool there) -> uint32_t {
+				auto at_byte = [k](uint32_t word) { return (float)((word >> (8 * k)) & 255u); };
+				const float tnx = dm_fmaf(at_byte(nxw), gx, cx) * inv.x, tfx = dm_fmaf(at_byte(fxw), gx, cx) * inv.x;
+				const float tny = dm_fmaf(at_byte(nyw), gy, cy) * inv.y, tfy = dm_fmaf(at_byte(fyw), gy, cy) * inv.y;
+				const float tnz = dm_fmaf(at_byte(nzw), gz, cz) * inv.z, tfz = dm_fmaf(at_byte(fzw), gz, cz) * inv.z;
+				const float tn = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(tnx, tny), tnz), 0.0f);
+				const float tf = __builtin_fminf(__builtin_fminf(__builtin_fminf(tfx, tfy), tfz), tmin);
+				const bool hit = tn <= tf * 1.000001f && there;
+				return ((hit ? f2u(tn) : SRT_BVH_KEY_INF) & ~SRT_BVH_TAG_MASK) | ((tags >> (8 * k)) & 255u);
+			};
+			k0 = child(0, true), k1 = child(1, true), k2 = child(2, nk > 2u), k3 = child(3, nk > 3u);
 			inner = true;
 		}
 		}

@@ -268,6 +268,61 @@ struct BvhBuilder {
 		std::vector<uint32_t> dest;
 		uint32_t root = SRT_BVH_NONE, need = 0;
 	};
+	// The boxes of an inner block as bytes (device_types.h): bound = fmaf(q, 2^e, origin) per axis, rounded outwards and CHECKED in
+	// exactly that arithmetic, the grid coarsened until every upper bound fits a byte. Non-finite extents (hostile input in
+	// all-embracing boxes) end on the coarsest grid, where upper bounds overflow to +inf: still a box that contains the child.
+	static void quantise(const std::vector<BvhNode> &c, const uint32_t *kids, uint32_t nk, uint32_t tags, uint32_t first, uint32_t *blk) {
+		float origin[3];
+		uint32_t expo[3];
+		uint8_t qlo[3][4], qhi[3][4];
+		for (int a = 0; a < 3; a++) {
+			origin[a] = FLT_MAX;
+			float top = -FLT_MAX;
+			for (uint32_t k = 0; k < nk; k++) origin[a] = std::min(origin[a], c[kids[k]].lo[a]), top = std::max(top, c[kids[k]].hi[a]);
+			if (!(origin[a] == origin[a])) origin[a] = -FLT_MAX; // (NaN boxes of hostile input)
+			int e = -126;
+			const float extent = top - origin[a];
+			if (extent > 0.0f) {
+				int ex = 0;
+				(void)std::frexp(extent / 255.0f, &ex); // extent / 255 = m * 2^ex, m in [0.5, 1): 2^ex is the first power of two above it
+				e = std::isfinite(extent) ? ex : 126;
+			}
+			for (;; e++) {
+				if (e < -126) e = -126;
+				if (e > 127) e = 127;
+				const float scale = std::ldexp(1.0f, e);
+				bool fits = true;
+				for (uint32_t k = 0; k < nk && fits; k++) {
+					const float lo = c[kids[k]].lo[a], hi = c[kids[k]].hi[a];
+					const float fl = std::floor((lo - origin[a]) / scale);
+					int ql = fl > 255.0f ? 255 : (fl > 0.0f ? (int)fl : 0);
+					while (ql > 0 && !(std::fmaf((float)ql, scale, origin[a]) <= lo)) ql--;
+					const float fh = std::ceil((hi - origin[a]) / scale);
+					int qh = fh > 255.0f ? 256 : (fh > 0.0f ? (int)fh : 0);
+					while (qh <= 255 && !(std::fmaf((float)qh, scale, origin[a]) >= hi)) qh++;
+					if (qh > 255) fits = false;
+					qlo[a][k] = (uint8_t)ql, qhi[a][k] = (uint8_t)(qh & 255);
+				}
+				if (fits || e == 127) { // (e == 127: 255 * 2^127 overflows every finite bound; keep what we have, q = 255 gives +inf)
+					if (!fits)
+						for (uint32_t k = 0; k < nk; k++) qhi[a][k] = 255;
+					expo[a] = (uint32_t)(e + 127);
+					break;
+				}
+			}
+		}
+		for (int a = 0; a < 3; a++) memcpy(&blk[a], &origin[a], 4);
+		blk[3] = expo[0] | (expo[1] << 8) | (expo[2] << 16) | (nk << 24);
+		for (int a = 0; a < 3; a++) {
+			blk[4 + a] = 0u, blk[7 + a] = 0u;
+			for (uint32_t k = 0; k < 4; k++) {
+				blk[4 + a] |= (uint32_t)(k < nk ? qlo[a][k] : 255u) << (8 * k); // (an empty slot: lo above hi; the walk counts the slots)
+				blk[7 + a] |= (uint32_t)(k < nk ? qhi[a][k] : 0u) << (8 * k);
+			}
+		}
+		blk[10] = tags;
+		blk[11] = first;
+	}
 	// fills block `self` (already allocated) from node ci; returns the reference to it
 	static uint32_t fold_node(const std::vector<BvhNode> &c, uint32_t ci, uint32_t self, bool balanced, Wide &w, uint32_t &need) {
 		const BvhNode &nd = c[ci];
@@ -309,27 +364,16 @@ struct BvhBuilder {
 		uint32_t deepest = 0;
 		uint32_t tags = 0;
 		for (uint32_t k = 0; k < 4; k++) {
-			const float fmax = FLT_MAX, fmin = -FLT_MAX;
-			if (k >= nk) { // an empty slot: a box no ray passes (lo > hi), whatever its direction's signs
-				uint32_t *blk = w.blocks.data() + 32 * (size_t)self;
-				for (int a = 0; a < 3; a++) memcpy(&blk[8 * a + k], &fmax, 4), memcpy(&blk[8 * a + 4 + k], &fmin, 4);
+			if (k >= nk) {
 				tags |= k << (8 * k);
 				continue;
 			}
 			uint32_t sub = 0;
 			const uint32_t ref = fold_node(c, kids[k], first + k, balanced, w, sub); // may grow w.blocks: index, do not keep pointers
 			if (sub > deepest) deepest = sub;
-			uint32_t *blk = w.blocks.data() + 32 * (size_t)self;
-			const BvhNode &kid = c[kids[k]];
-			for (int a = 0; a < 3; a++) {
-				memcpy(&blk[8 * a + k], &kid.lo[a], 4);
-				memcpy(&blk[8 * a + 4 + k], &kid.hi[a], 4);
-			}
 			tags |= SRT_BVH_TAG(ref, k) << (8 * k);
 		}
-		w.blocks[32 * (size_t)self + 24] = tags;
-		w.blocks[32 * (size_t)self + 25] = first;
-		w.blocks[32 * (size_t)self + 26] = nk;
+		quantise(c, kids, nk, tags, first, w.blocks.data() + 32 * (size_t)self);
 		need = deepest + (nk - 1u);
 		return self;
 	}
@@ -783,7 +827,7 @@ static int prepare_scene(srt_tracer *t, ScenePrep &sp, const srt_shape *shapes, 
 				if ((uint64_t)b0 + wd.blocks.size() / 32 > SRT_BVH_INDEX_MAX) return fail(t, SRT_ERR_INVALID, "srt_update_scene: too many BVH blocks");
 				if (wd.need > SRT_BVH_STACK_CAP) return fail(t, SRT_ERR_INVALID, "srt_update_scene: BVH deeper than the walk's stack"); // unreachable below 2^28 triangles
 				bvh_blocks.insert(bvh_blocks.end(), wd.blocks.begin(), wd.blocks.end());
-				for (uint32_t ib : wd.inner) bvh_blocks[32 * (size_t)(b0 + ib) + 25] += b0; // where the block's children lie
+				for (uint32_t ib : wd.inner) bvh_blocks[32 * (size_t)(b0 + ib) + SRT_BVH_FIRST_DWORD] += b0; // where the block's children lie
 				bvh_dest.resize(r0 + (size_t)m.num_triangles);
 				for (uint32_t r = 0; r < m.num_triangles; r++) bvh_dest[r0 + r] = wd.dest[r] + (b0 << 2);
 				bvh_canonical_nodes += ent->nodes.size();

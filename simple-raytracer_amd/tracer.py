@@ -69,8 +69,9 @@ BVH_STACK_CAP = 64
 
 def bvh_wide_host(model_shape, triangles, force_balanced=False):
     """The four-wide hierarchy the kernel walks for one model shape record (csrc/device_types.h): dict with
-    blocks (n x 32 uint32; view as float32 for the boxes), dest (per record: leaf block << 2 | slot), root,
-    stack_need, balanced. Host only: no GPU needed; leaf blocks come back empty (the device writes the triangles)."""
+    blocks (n x 32 uint32; an inner block: origin, grid exponents + count, boxes as bytes, tags, first), dest (per record:
+    leaf block << 2 | slot), root, stack_need, balanced. Host only: no GPU needed; leaf blocks come back empty (the device
+    writes the triangles)."""
     lib = load_library()
     lib.srt_bvh_wide_host.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t,
                                       C.POINTER(C.c_size_t), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_int)]
@@ -78,12 +79,13 @@ def bvh_wide_host(model_shape, triangles, force_balanced=False):
     shape[0] = model_shape
     tris = R.as_records(triangles, R.TRIANGLE)
     n, root, need, bal = C.c_size_t(0), C.c_uint32(0), C.c_uint32(0), C.c_int(0)
-    rc = lib.srt_bvh_wide_host(_ptr(shape), _ptr(tris), len(tris), int(force_balanced), None, 0, None, 0, C.byref(n), None, None, None)
+    flags = int(bool(force_balanced))
+    rc = lib.srt_bvh_wide_host(_ptr(shape), _ptr(tris), len(tris), flags, None, 0, None, 0, C.byref(n), None, None, None)
     if rc:
         raise SrtError(f"srt_bvh_wide_host failed ({rc})")
     blocks = np.zeros((n.value, 32), np.uint32)
     dest = np.zeros(int(shape[0]["num_triangles"]), np.uint32)
-    rc = lib.srt_bvh_wide_host(_ptr(shape), _ptr(tris), len(tris), int(force_balanced), _ptr(blocks), len(blocks), _ptr(dest), len(dest),
+    rc = lib.srt_bvh_wide_host(_ptr(shape), _ptr(tris), len(tris), flags, _ptr(blocks), len(blocks), _ptr(dest), len(dest),
                                C.byref(n), C.byref(root), C.byref(need), C.byref(bal))
     if rc:
         raise SrtError(f"srt_bvh_wide_host failed ({rc})")

@@ -59,6 +59,22 @@ def check_boxes(nodes, order, wv):
         assert (v.min(axis=0) > nodes["lo"][i]).all() and (v.max(axis=0) < nodes["hi"][i]).all(), "boxes are padded"
 
 
+def inner_children(blocks, idx):
+    """(first, nk, tags[4], lo[4][3], hi[4][3]) of inner block idx (csrc/device_types.h): boxes as bytes on the block's power-of-two
+    grid -- origin in dwords 0-2, exponents and count in 3, lo bytes 4-6, hi bytes 7-9, tags 10, first 11; bound = fmaf(byte, 2^e,
+    origin) (the product is exact, the float64 sum rounds to float32 once: the kernel's fmaf up to double rounding)."""
+    b = blocks[idx]
+    assert not b[12:].any()
+    origin = b.view(np.float32)[0:3].astype(np.float64)
+    ex, nk = int(b[3]), int(b[3]) >> 24
+    scale = np.array([((ex >> (8 * a)) & 255) << 23 for a in range(3)], np.uint32).view(np.float32).astype(np.float64)
+    byte = lambda w, k: float((int(w) >> (8 * k)) & 255)
+    with np.errstate(all="ignore"):
+        lo = [np.array([byte(b[4 + a], k) * scale[a] + origin[a] for a in range(3)]).astype(np.float32) for k in range(4)]
+        hi = [np.array([byte(b[7 + a], k) * scale[a] + origin[a] for a in range(3)]).astype(np.float32) for k in range(4)]
+    return int(b[11]), nk, [(int(b[10]) >> (8 * k)) & 255 for k in range(4)], lo, hi
+
+
 def check_wide(wide, nodes, order, n_tris):
     """Every record sits in exactly one slot of one leaf block, references are in range and each block is referenced
     once, the four boxes of an inner block are boxes of the binary hierarchy, and no walk can have more than
@@ -70,7 +86,7 @@ def check_wide(wide, nodes, order, n_tris):
     fl = blocks.view(np.float32)
     seen = np.zeros(len(blocks), np.int32)
     slots = {}
-    boxes = {(tuple(nd["lo"]), tuple(nd["hi"])) for nd in nodes}
+    box_lo, box_hi = nodes["lo"].astype(np.float64), nodes["hi"].astype(np.float64)
     inner = leaves = 0
 
     def ref_of(tag, idx):  # a child's tag + block index in the form of the root reference
@@ -90,15 +106,18 @@ def check_wide(wide, nodes, order, n_tris):
             leaves += 1
             return 0
         inner += 1
-        tags, first, nk = [(int(blocks[idx, 24]) >> (8 * k)) & 255 for k in range(4)], int(blocks[idx, 25]), int(blocks[idx, 26])
-        assert 2 <= nk <= 4 and not blocks[idx, 27:].any() and first + nk <= len(blocks)
+        first, nk, tags, los, his = inner_children(blocks, idx)
+        assert 2 <= nk <= 4 and first + nk <= len(blocks)
         assert [t & 3 for t in tags] == [0, 1, 2, 3], "a tag carries its slot"
-        for k in range(nk):
-            lo = tuple(fl[idx, [k, 8 + k, 16 + k]])
-            hi = tuple(fl[idx, [4 + k, 12 + k, 20 + k]])
-            assert (lo, hi) in boxes
-        for k in range(nk, 4):  # empty slots: a box nothing passes, children are packed to the front
-            assert (fl[idx, [k, 8 + k, 16 + k]] == FLT_MAX).all() and (fl[idx, [4 + k, 12 + k, 20 + k]] == -FLT_MAX).all() and tags[k] == k
+        # every decoded box contains a box of the binary hierarchy and overshoots it by less than two cells of the block's grid
+        if len(box_lo) <= 4000 or inner % 97 == 0:  # (all blocks of small hierarchies, a sample of large ones)
+            cell = np.array([((int(blocks[idx, 3]) >> (8 * a)) & 255) << 23 for a in range(3)], np.uint32).view(np.float32).astype(np.float64)
+            for k in range(nk):
+                with np.errstate(all="ignore"):
+                    ok = ((box_lo >= los[k]) & (box_hi <= his[k]) & (box_lo - los[k] < 2 * cell + 1e-30) & (his[k] - box_hi < 2 * cell + 1e-30)).all(axis=1)
+                assert ok.any(), (idx, k)
+        for k in range(nk, 4):  # empty slots: lo above hi, children are packed to the front (the walk counts the slots)
+            assert all((int(blocks[idx, 4 + a]) >> (8 * k)) & 255 == 255 and (int(blocks[idx, 7 + a]) >> (8 * k)) & 255 == 0 for a in range(3)) and tags[k] == k
         return nk - 1 + max(need_of(ref_of(tags[k], first + k)) for k in range(nk))
 
     import sys
@@ -131,19 +150,20 @@ def walk(wide, rec_of_slot, org, d):
         if tag & 16:
             tested.extend(rec_of_slot[(idx << 2) | k] for k in range((tag >> 2) & 3))
         else:
-            first, keys = int(blocks[idx, 25]), []
+            first, nk, tags, los, his = inner_children(blocks, idx)
+            keys = []
             for k in range(4):
-                lo, hi = fl[idx, [k, 8 + k, 16 + k]], fl[idx, [4 + k, 12 + k, 20 + k]]
-                near, far = np.where(neg, hi, lo), np.where(neg, lo, hi)  # what the lane's addresses pick
+                lo, hi = los[k], his[k]
+                near, far = np.where(neg, hi, lo), np.where(neg, lo, hi)  # what the lane's selects pick
                 with np.errstate(all="ignore"):
                     tn = max(((near - org) * inv).max(), f(0))
                     tf = ((far - org) * inv).min()
-                    hit = tn <= tf * f(1.000001)
+                    hit = tn <= tf * f(1.000001) and k < nk
                 bits = int(np.array([tn], f).view(np.uint32)[0]) if hit else 0x7F800000
-                keys.append((bits & ~31) | ((int(blocks[idx, 24]) >> (8 * k)) & 255))
+                keys.append((bits & ~31) | tags[k])
             keys.sort()
             enter = [k for k in keys if k < 0x7F800000]
-            assert all(k & 3 < int(blocks[idx, 26]) for k in enter), "an empty slot was entered"
+            assert all(k & 3 < nk for k in enter), "an empty slot was entered"
             if enter:
                 cur = (first + (enter[0] & 3), enter[0])
                 stack.extend((k, first) for k in reversed(enter[1:]))

@@ -70,11 +70,11 @@ def _both(T, sky, shapes, tris, mats, rd):
     return res
 
 
-@pytest.mark.parametrize("scene,w,h,spp", [("mesh2", 320, 180, 4), ("mesh100k", 160, 90, 2), ("mesh100k_smooth", 96, 54, 2)])
+@pytest.mark.parametrize("scene,w,h,spp", [("mesh2", 320, 180, 4), ("mesh6k_smooth", 160, 90, 4), ("mesh100k", 160, 90, 2), ("mesh100k_smooth", 96, 54, 2)])
 def test_bvh_equals_array_scan(scene, w, h, spp, T, sky):
     """BASELINE configs[2] / configs[4] geometry at sizes the brute-force kernel finishes in a
     second: same canvas bits, same ray / sky / path counts, far fewer triangle tests."""
-    shapes, tris, mats = {"mesh2": lambda: S.mesh_scene(2), "mesh100k": lambda: S.mesh_scene(1, 224, 224, smooth=False),
+    shapes, tris, mats = {"mesh2": lambda: S.mesh_scene(2), "mesh6k_smooth": lambda: S.mesh_scene(1, 56, 55, smooth=True), "mesh100k": lambda: S.mesh_scene(1, 224, 224, smooth=False),
                           "mesh100k_smooth": lambda: S.mesh_scene(1, 224, 224, smooth=True)}[scene]()
     rd = R.render_data(w, h, spp, 10, camera_to_world=S.default_camera(), time=31337)
     (c0, k0, i0), (c1, k1, i1) = _both(T, sky, shapes, tris, mats, rd)

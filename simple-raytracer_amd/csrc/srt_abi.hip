@@ -1319,11 +1319,12 @@ int srt_trace_fused(srt_tracer *t, const srt_render_data *options, uint8_t *fuse
 		// sub-jobs 4,524 / 4,508 / 4,593 ms.
 		unsigned long long cap_subs = 5ull;
 		if (t->num_models > 0) {
-			cap_subs = ((t->bvh_active ? 3ull * nbs : 5ull * nbs / 2ull) + sub - 1ull) / sub;
+			cap_subs = (5ull * nbs / 2ull + sub - 1ull) / sub;
 			// (BVH, sub-jobs of 64: chunks of 10 / 16 sub-jobs configs[2] 39.3 / 35.7 ms, configs[4] 35.7-36.5 / 36.5 ms; sub-jobs of 128
-			// and 8: 37.0 / 36.3. Round 4's walk, chunks of 6 / 8 / 10 / 12 / 16 / 24 / 32 sub-jobs: configs[2] 47.1 / 40.7 / 37.5 /
-			// 35.8 / 33.7 / 33.5 / 36.0 ms, configs[4] 36.0 / 33.6 / 32.4 / 32.2 / 33.4 / 36.9 / 41.0: three pixels' worth)
-			const unsigned long long most = t->bvh_active ? 24ull : 8ull;
+			// and 8: 37.0 / 36.3. Round 4's walks, chunks of 6 / 8 / 10 / 12 / 16 / 24 / 32 sub-jobs -- float boxes: configs[2] 47.1 / 40.7 /
+			// 37.5 / 35.8 / 33.7 / 33.5 / 36.0 ms, configs[4] 36.0 / 33.6 / 32.4 / 32.2 / 33.4 / 36.9 / 41.0; boxes as bytes: 46.7 / 40.3 / 37.0 /
+			// 35.3 / 33.2 / 33.7 / 35.4 and 33.9 / 31.6 / 30.6 / 31.2 / 31.7 / 36.4 / 40.2: two and a half pixels' worth, at most 16)
+			const unsigned long long most = t->bvh_active ? 16ull : 8ull;
 			cap_subs = cap_subs < 2ull ? 2ull : (cap_subs > most ? most : cap_subs);
 		}
 		if (const char *env = dev_env("SRT_JOB_CAP_SUBS"))

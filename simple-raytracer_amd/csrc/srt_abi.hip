@@ -271,10 +271,17 @@ struct BvhBuilder {
 	// The boxes of an inner block as bytes (device_types.h): bound = fmaf(q, 2^e, origin) per axis, rounded outwards and CHECKED in
 	// exactly that arithmetic, the grid coarsened until every upper bound fits a byte. Non-finite extents (hostile input in
 	// all-embracing boxes) end on the coarsest grid, where upper bounds overflow to +inf: still a box that contains the child.
-	static void quantise(const std::vector<BvhNode> &c, const uint32_t *kids, uint32_t nk, uint32_t tags, uint32_t first, uint32_t *blk) {
+	template <class Fma>
+	static inline __attribute__((always_inline)) void quantise_body(const std::vector<BvhNode> &c, const uint32_t *kids, uint32_t nk, uint32_t tags, uint32_t first, uint32_t *blk, Fma fmaf_any) {
 		float origin[3];
 		uint32_t expo[3];
 		uint8_t qlo[3][4], qhi[3][4];
+		auto pow2 = [](int e) { // 2^e as a float, -126 <= e <= 127
+			const uint32_t bits = (uint32_t)(e + 127) << 23;
+			float f;
+			memcpy(&f, &bits, 4);
+			return f;
+		};
 		for (int a = 0; a < 3; a++) {
 			origin[a] = FLT_MAX;
 			float top = -FLT_MAX;
@@ -290,16 +297,18 @@ struct BvhBuilder {
 			for (;; e++) {
 				if (e < -126) e = -126;
 				if (e > 127) e = 127;
-				const float scale = std::ldexp(1.0f, e);
+				const float scale = pow2(e);
+				const double inv_scale = std::ldexp(1.0, -e); // (exact; in double so that 2^126 has a reciprocal)
 				bool fits = true;
 				for (uint32_t k = 0; k < nk && fits; k++) {
 					const float lo = c[kids[k]].lo[a], hi = c[kids[k]].hi[a];
-					const float fl = std::floor((lo - origin[a]) / scale);
-					int ql = fl > 255.0f ? 255 : (fl > 0.0f ? (int)fl : 0);
-					while (ql > 0 && !(std::fmaf((float)ql, scale, origin[a]) <= lo)) ql--;
-					const float fh = std::ceil((hi - origin[a]) / scale);
-					int qh = fh > 255.0f ? 256 : (fh > 0.0f ? (int)fh : 0);
-					while (qh <= 255 && !(std::fmaf((float)qh, scale, origin[a]) >= hi)) qh++;
+					const double fl = ((double)lo - (double)origin[a]) * inv_scale; // >= 0: origin is the smallest lo
+					int ql = fl >= 255.0 ? 255 : (fl > 0.0 ? (int)fl : 0);       // (NaN: 0)
+					while (ql > 0 && !(fmaf_any((float)ql, scale, origin[a]) <= lo)) ql--;
+					const double fh = ((double)hi - (double)origin[a]) * inv_scale;
+					int qh = fh > 255.0 ? 256 : (fh > 0.0 ? (int)fh + ((double)(int)fh < fh ? 1 : 0) : 0);
+					if (!(fh == fh)) qh = 256;
+					while (qh <= 255 && !(fmaf_any((float)qh, scale, origin[a]) >= hi)) qh++;
 					if (qh > 255) fits = false;
 					qlo[a][k] = (uint8_t)ql, qhi[a][k] = (uint8_t)(qh & 255);
 				}
@@ -322,6 +331,16 @@ struct BvhBuilder {
 		}
 		blk[10] = tags;
 		blk[11] = first;
+	}
+	// The check wants fmaf as the device rounds it. glibc's fmaf is a call into a software path on some hosts (85 ns: 45 ms of a
+	// 10^5-triangle hierarchy's 528,000 checks); a CPU with FMA does it in one instruction, inlined into a copy of the function.
+	__attribute__((target("fma"))) static void quantise_hw(const std::vector<BvhNode> &c, const uint32_t *kids, uint32_t nk, uint32_t tags, uint32_t first, uint32_t *blk) {
+		quantise_body(c, kids, nk, tags, first, blk, [](float a, float b, float x) __attribute__((target("fma"))) { return __builtin_fmaf(a, b, x); });
+	}
+	static void quantise(const std::vector<BvhNode> &c, const uint32_t *kids, uint32_t nk, uint32_t tags, uint32_t first, uint32_t *blk) {
+		static const bool hw = __builtin_cpu_supports("fma");
+		if (hw) quantise_hw(c, kids, nk, tags, first, blk);
+		else quantise_body(c, kids, nk, tags, first, blk, [](float a, float b, float x) { return std::fmaf(a, b, x); });
 	}
 	// fills block `self` (already allocated) from node ci; returns the reference to it
 	static uint32_t fold_node(const std::vector<BvhNode> &c, uint32_t ci, uint32_t self, bool balanced, Wide &w, uint32_t &need) {

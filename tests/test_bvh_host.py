@@ -275,6 +275,48 @@ def test_a_hierarchy_too_deep_for_the_stack_is_rebuilt_balanced():
     assert deepest <= forced["stack_need"]
 
 
+@pytest.mark.parametrize("offset,scale", [((0, 0, 0), 1.0), ((3e6, -2e6, 1e6), 1.0), ((0.5, 0.25, -0.125), 2.0 ** -60), ((1e30, 0, 0), 1e25)])
+def test_byte_boxes_of_flat_far_tiny_and_huge_meshes(offset, scale):
+    """What the quantiser of the inner blocks has to get right at the edges: a planar mesh (zero extent on one axis: the
+    coarsest useful grid there is the finest), coordinates millions of model sizes from the origin (the grid's origin
+    swallows the bytes' low bits), a mesh of 2^-60 and one of 10^25 units: every decoded box contains its child's box,
+    within two cells, and the float32 walk still reaches every triangle a double-precision ray hits."""
+    n = 24
+    tris = np.zeros(2 * n * n, R.TRIANGLE)
+    k = 0
+    for i in range(n):
+        for j in range(n):
+            p = [(i, j, 0), (i + 1, j, 0), (i, j + 1, 0), (i + 1, j + 1, 0)]
+            tris[k] = R.flat_triangle((0, 0, 1), p[0], p[1], p[2])
+            tris[k + 1] = R.flat_triangle((0, 0, 1), p[1], p[3], p[2])
+            k += 2
+    xf = R.mat_mul(R.translate(offset), R.scale_matrix((scale, scale, scale)))
+    shape = R.model(0, tris, 0, len(tris), xf)
+    nodes, order = T.bvh_build_host(shape, tris)
+    check_structure(nodes, order, len(tris))
+    wide = T.bvh_wide_host(shape, tris)
+    check_wide(wide, nodes, order, len(tris))
+    wv = world_vertices(shape, tris)
+    rec_of_slot = {int(s): r for r, s in enumerate(wide["dest"])}
+    rec_of = np.empty(len(order), np.int64)
+    rec_of[order] = np.arange(len(order))
+    rng = np.random.RandomState(5)
+    centre = wv.reshape(-1, 3).mean(axis=0)
+    n_hits = 0
+    for _ in range(120):
+        target = wv[rng.randint(len(wv))].mean(axis=0)
+        org = target + np.array([rng.normal() * 5, rng.normal() * 5, 10 + rng.uniform(0, 30)]) * scale
+        d = target - org
+        d /= np.linalg.norm(d)
+        tested, steps, deepest = walk(wide, rec_of_slot, org, d)
+        assert steps <= len(wide["blocks"]) and deepest <= wide["stack_need"]
+        hit = true_hits(wv, org.astype(np.float32).astype(np.float64), d.astype(np.float32).astype(np.float64))
+        missing = set(rec_of[hit].tolist()) - set(tested)
+        assert not missing, (offset, scale, sorted(missing))
+        n_hits += len(hit)
+    assert n_hits > 20 or scale != 1.0  # (far from the origin float32 rays are coarse: hits are fewer, never untested)
+
+
 def test_degenerate_inputs():
     tris = np.zeros(8, R.TRIANGLE)
     for i in range(8):  # eight copies of ONE triangle: coincident centroids force the index split

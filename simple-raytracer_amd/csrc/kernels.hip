@@ -723,11 +723,11 @@ __device__ __forceinline__ void test_triangles(const float *__restrict__ wtris, 
 // ---- BVH walk (opt-in; device_types.h "wide hierarchy") ------------------------------------
 // Per lane: rays of a wave are incoherent after the first bounce, so blocks come through per-lane
 // loads. What binds the walk is the CU's vector memory pipe -- ONE address unit for its 20 waves, busy
-// three quarters of a launch; a load costs per instruction, whatever its width and however few lanes
-// execute it (profiles/r04_bvh_vmem_probe.md; per lane that executes it: scripts/microbench/ta_rates.hip) -- so a step
-// is built around as few loads as the data allows: an inner block holds the boxes of FOUR children as bytes on a grid of
-// its own (48 bytes: three quarters, a ray takes about a quarter of the steps of a binary walk), a leaf block up to three
-// triangles (27 dwords: seven quarters, fetched by the lanes that stand on a leaf).
+// two thirds of a launch; a divergent load costs it ~7 ns plus ~0.3 ns per lane that executes it, whatever
+// its width (profiles/r04_bvh_vmem_probe.md, scripts/microbench/ta_rates.hip) -- so a step is built around as
+// few lane-loads as the data allows: an inner block holds the boxes of FOUR children as bytes on a grid of its
+// own (48 bytes: three quarters; a ray takes about a quarter of the steps of a binary walk), a leaf block up to
+// three triangles (27 dwords: seven quarters, four of them fetched only by the lanes that stand on a leaf).
 // Children are visited nearest first by their entry distance; the others wait, with that distance, on a
 // per-lane stack in scratch memory whose top entry lives in registers.
 // Same Moller-Trumbore as the array scan, so every accepted hit has the same t; what the walk must
@@ -757,7 +757,7 @@ __device__ __forceinline__ void bvh_order2(uint32_t &a, uint32_t &b) {
 }
 
 #ifndef SRT_BVH_PUSH_FORM
-#define SRT_BVH_PUSH_FORM 1 // 0: three unconditional stores, the idle ones into a spare slot: 37.7 / 37.8 ms against 34.7 / 33.9 -- the walk is bound by what it sends through the vector memory pipe
+#define SRT_BVH_PUSH_FORM 1 // 0: three unconditional stores, the idle ones into a spare slot: 37.7 / 37.8 ms against 34.7 / 33.9 (measured on the float-box walk)
 #endif
 template <bool COUNT_TRIS>
 __device__ __forceinline__ void walk_bvh(const float4 *__restrict__ blocks, BvhStackEntry *__restrict__ stack, uint32_t root, f3 org, f3 dir, int idx,

@@ -91,7 +91,7 @@ DEV_LIB = LIBDIR / "variants" / "dev" / "libsrt_hip.so"
 
 def build_dev(force=False):
     """The -DSRT_DEV_KNOBS build of the same sources -> lib/variants/dev/libsrt_hip.so: reads the development knobs
-    (SRT_WAVES_PER_CU, SRT_SCAN_PAIRS, SRT_JOB_CAP_SUBS, SRT_POOL_BLOCKS, SRT_NO_SCAN_POOL) from the environment, which the
+    (SRT_WAVES_PER_CU, SRT_SCAN_PAIRS, SRT_JOB_CAP_SUBS, SRT_ITEMS_PER_WAVE, SRT_FORCE_BATCH, SRT_POOL_BLOCKS, SRT_NO_SCAN_POOL) from the environment, which the
     product library does not. For the tests that force rare paths and for scripts/."""
     deps = [CSRC / s for s in SOURCES] + [(CSRC / h).resolve() for h in HEADERS] + [Path(__file__)]
     if not force and DEV_LIB.exists() and all(d.stat().st_mtime <= DEV_LIB.stat().st_mtime for d in deps):

@@ -544,7 +544,7 @@ int srt_partition_unpermute(const void *gathered, void *image, int height, int w
 }
 
 // Development knobs (scheduling experiments and tests that force rare paths: SRT_WAVES_PER_CU, SRT_SCAN_PAIRS, SRT_JOB_CAP_SUBS,
-// SRT_POOL_BLOCKS, SRT_NO_SCAN_POOL) are read from the environment by -DSRT_DEV_KNOBS builds only (build.py build_dev():
+// SRT_ITEMS_PER_WAVE, SRT_FORCE_BATCH, SRT_POOL_BLOCKS, SRT_NO_SCAN_POOL) are read from the environment by -DSRT_DEV_KNOBS builds only (build.py build_dev():
 // lib/variants/dev/). The product library's scheduling does not depend on the caller's environment.
 #ifdef SRT_DEV_KNOBS
 static const char *dev_env(const char *name) { return getenv(name); }

@@ -267,6 +267,10 @@ struct BvhBuilder {
 		std::vector<uint32_t> inner;
 		std::vector<uint32_t> dest;
 		uint32_t root = SRT_BVH_NONE, need = 0;
+		struct Job { // an inner block whose boxes are still to be quantised (fold_wide does them on several threads)
+			uint32_t self, kids[4], nk, tags, first;
+		};
+		std::vector<Job> jobs;
 	};
 	// The boxes of an inner block as bytes (device_types.h): bound = fmaf(q, 2^e, origin) per axis, rounded outwards and CHECKED in
 	// exactly that arithmetic, the grid coarsened until every upper bound fits a byte. Non-finite extents (hostile input in
@@ -392,7 +396,7 @@ struct BvhBuilder {
 			if (sub > deepest) deepest = sub;
 			tags |= SRT_BVH_TAG(ref, k) << (8 * k);
 		}
-		quantise(c, kids, nk, tags, first, w.blocks.data() + 32 * (size_t)self);
+		w.jobs.push_back({self, {kids[0], kids[1], nk > 2 ? kids[2] : 0u, nk > 3 ? kids[3] : 0u}, nk, tags, first});
 		need = deepest + (nk - 1u);
 		return self;
 	}
@@ -401,8 +405,32 @@ struct BvhBuilder {
 		w.dest.assign(records, 0u);
 		w.root = SRT_BVH_NONE, w.need = 0;
 		if (c.empty()) return;
+		w.blocks.reserve(32 * c.size()); // (every node of the binary hierarchy becomes at most one block)
+		w.inner.reserve(c.size() / 2 + 1), w.jobs.reserve(c.size() / 2 + 1);
 		w.blocks.resize(32, 0u);
+		w.jobs.clear();
 		w.root = fold_node(c, 0u, 0u, balanced, w, w.need);
+		// the blocks' boxes: every inner block by itself (reads the binary nodes, writes its own 48 bytes), large hierarchies on up
+		// to eight threads (10^5 triangles: 22k blocks x 24 bounds rounded outwards and checked)
+		uint32_t *blocks = w.blocks.data();
+		const size_t nj = w.jobs.size();
+		auto run = [&](size_t lo, size_t hi) {
+			for (size_t i = lo; i < hi; i++) {
+				const Wide::Job &j = w.jobs[i];
+				quantise(c, j.kids, j.nk, j.tags, j.first, blocks + 32 * (size_t)j.self);
+			}
+		};
+		const size_t parts = nj >= 4096 ? 8 : 1;
+		std::vector<std::future<void>> futs;
+		try {
+			for (size_t t = 1; t < parts; t++) futs.push_back(std::async(std::launch::async, run, nj * t / parts, nj * (t + 1) / parts));
+		} catch (const std::system_error &) { // no more threads: the rest is done here
+		}
+		run(0, nj / parts);
+		for (size_t t = futs.size() + 1; t < parts; t++) run(nj * t / parts, nj * (t + 1) / parts);
+		for (auto &f : futs) f.get();
+		w.jobs.clear();
+		w.jobs.shrink_to_fit();
 	}
 
 	// Appends the model's nodes and triangle order; returns the root's index.
